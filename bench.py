@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py — the reference's headline metric on MI355X: Mcell-updates/s (and achieved HBM GB/s)
+of the per-step advection–diffusion sweep on a 16384 x 16384 fp64 grid at 1/2/4/8 GPUs.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (reference src/main.cpp:101-109: halo exchange, boundary
+fill, fused copy+diffusion+advection sweep, swap) over the whole grid; the grid is resident in
+HBM when the timed region starts (gaussian hotspot written on the device).  N > 1 is STRONG
+scaling of the same global grid: one process per GPU, 2D block decomposition by the
+MPI_Dims_create rule, halos over RCCL send/recv on a second HIP stream.  torch.distributed
+(gloo) is only the control plane: unique-id broadcast, barrier, max-over-ranks.
+
+Rank 0 prints ONE JSON line.  Extra objects: `roofline` (dominant kernel = the fused sweep;
+algorithmic bytes = 16 B per cell update; duration from HIP events on the compute stream
+around every sweep launch of the timed region) and, at N = 1, `cpu_baseline` (the compiled
+reference objects, oracle/_ref/ref_run under mpirun, on a bounded sample — or the oracle port
+when that binary cannot run).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BYTES_PER_CELL = 16.0       # one 8-byte read of u + one 8-byte write of u'
+
+# BASELINE.json `metric`: 16384^2 fp64; physics of configs[2]/[3]
+NX = NY = 16384
+PHYS = dict(D=0.05, vx=0.5, vy=0.25, dt=0.1)
+BC = "dddd"
+
+
+def cpu_baseline(cores: int, budget_s: float = 25.0):
+    """Reference CPU path on the host cores, bounded sample of the same workload."""
+    from oracle import cpu_oracle as ora
+    nx = ny = int(os.environ.get("CSIM_BENCH_CPU_N", NX))
+    steps = int(os.environ.get("CSIM_BENCH_CPU_STEPS", 4))
+    if ora.have_reference():
+        try:
+            t0 = time.time()
+            out = ora.ref_run("run", np_ranks=cores, timeout=600, nx=nx, ny=ny, steps=steps,
+                              bc=BC, ic="gaussian", **PHYS)
+            wall = time.time() - t0
+            m = re.search(r"timing: total_max=([0-9.eE+-]+) s", out)
+            loop_s = float(m.group(1))
+            return dict(value=nx * ny * steps / loop_s / 1e6, unit="Mcell-updates/s", cores=cores,
+                        kind="reference",
+                        sample=f"{nx}x{ny} fp64, {steps} steps, oracle/_ref/ref_run (reference "
+                               f"objects, g++ -O2) under mpirun -np {cores}; loop {loop_s:.2f} s, "
+                               f"whole run {wall:.1f} s")
+        except Exception as e:  # mpirun unusable on this box: fall back to the port
+            sys.stderr.write(f"[bench] reference baseline unavailable ({e}); using the port\n")
+    w = ora.World(cores, nx, ny, 1.0, 1.0)
+    w.gaussian()
+    secs = w.run(PHYS["D"], PHYS["vx"], PHYS["vy"], PHYS["dt"], ora.bc_codes(BC), steps,
+                 threads=cores)
+    return dict(value=nx * ny * steps / secs / 1e6, unit="Mcell-updates/s", cores=cores, kind="port",
+                sample=f"{nx}x{ny} fp64, {steps} steps, oracle/cpu_stepper.c with {cores} threads "
+                       f"(one tile per thread); loop {secs:.2f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--nx", type=int, default=NX)
+    ap.add_argument("--ny", type=int, default=NY)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--rows-per-chunk", type=int, default=0)
+    ap.add_argument("--prefetch", type=int, default=0)
+    ap.add_argument("--no-overlap", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+
+    # CPU baseline first: it forks mpirun, which must happen before this process touches the GPU
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cores = min(16, os.cpu_count() or 1)
+        cpu = cpu_baseline(cores)
+
+    import torch  # noqa: F401  (plumbing: torch.distributed control plane; also pins ONE HIP runtime)
+    import torch.distributed as dist
+    from __graft_entry__ import load_package
+    csim = load_package()
+    csim.lib()
+    csim.set_device(local_rank)
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    dec = csim.decomp_init(world, rank, args.nx, args.ny)
+    st = csim.Stepper(dec, 1.0, 1.0, csim.bc_codes(BC), 0.0)
+    if world > 1:
+        box = [csim.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        st.comm_init(box[0])
+    for key, val in (("variant", args.variant), ("rows_per_chunk", args.rows_per_chunk),
+                     ("prefetch", args.prefetch), ("overlap", 0 if args.no_overlap else 1)):
+        st.set_option(key, val)
+    st.init_gaussian(1.0, 0.05, 0.5, 0.5)
+    dt = min(PHYS["dt"], csim.safe_dt(1.0, 1.0, PHYS["vx"], PHYS["vy"], PHYS["D"]))
+
+    def barrier():
+        st.sync()
+        if world > 1:
+            dist.barrier()
+
+    st.run(PHYS["D"], dt, PHYS["vx"], PHYS["vy"], args.warmup)
+    barrier()
+    st.set_option("profile", 1)
+    st.reset_timers()
+    t0 = time.perf_counter()
+    st.run(PHYS["D"], dt, PHYS["vx"], PHYS["vy"], args.steps)
+    st.sync()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms, launches = st.kernel_time()
+    mn, mx = st.minmax()
+    st.close()
+    if world > 1:
+        km = torch.tensor([kern_ms / max(launches, 1)], dtype=torch.float64)
+        dist.all_reduce(km, op=dist.ReduceOp.MAX)
+        kern_avg_ms = float(km.item())
+        dist.destroy_process_group()
+    else:
+        kern_avg_ms = kern_ms / max(launches, 1)
+
+    if rank == 0:
+        cells = float(args.nx) * float(args.ny)
+        value = cells * args.steps / elapsed / 1e6
+        local_cells = float(dec.nx_local) * float(dec.ny_local)
+        ach = local_cells * BYTES_PER_CELL / (kern_avg_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if world == 1 and os.path.exists(tfile):
+            try:
+                tj = json.load(open(tfile))
+                if tj.get("nx") == args.nx and tj.get("ny") == args.ny:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "Mcell-updates/sec (16384^2 fp64 advection-diffusion sweep)",
+            "value": value,
+            "unit": "Mcell-updates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.nx}x{args.ny} fp64 gaussian hotspot, D={PHYS['D']} "
+                            f"v=({PHYS['vx']},{PHYS['vy']}) dt={dt} dx=dy=1, all-Dirichlet(0), "
+                            f"decomp {dec.dims[0]}x{dec.dims[1]} (local {dec.nx_local}x{dec.ny_local}), "
+                            f"halo overlap {'off' if args.no_overlap else 'on'}",
+                "hbm_gbs_whole_job": cells * args.steps * BYTES_PER_CELL / elapsed / 1e9,
+                "field_min_max_after_run": [mn, mx],
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": ach,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "kernel": "k_sweep (fused copy+diffusion+advection)",
+                "kernel_avg_ms": kern_avg_ms,
+                "launches_timed": launches,
+                "algorithmic_bytes_per_launch": local_cells * BYTES_PER_CELL,
+            },
+        }
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+        print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

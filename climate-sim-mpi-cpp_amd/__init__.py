@@ -1,0 +1,356 @@
+"""climate-sim-mpi-cpp_amd — thin ctypes front end of the C ABI in include/csim.h.
+
+The product is the C-ABI shared library (csrc/ -> lib/libcsim.so: hand-written gfx950 HIP
+kernels + RCCL halo exchange) and the C++17 headers in include/climate/ that mirror the
+reference's own interface.  This module only exists so that tests/, bench.py and
+__graft_entry__.py can reach that ABI from Python; names follow the reference
+(`Field`, `Decomp2D`, `BCConfig`, `apply_boundary`, `diffusion_step`, `advection_step`,
+`exchange_halos`, `safe_dt` — reference include/*.hpp).
+
+There is no CPU fallback: if lib/libcsim.so is missing or no gfx950 device is usable the
+calls raise.  (The directory name contains '-', so import it through
+``__graft_entry__.load_package()``, which registers it as ``climate_sim_mpi_cpp_amd``.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB_PATH = os.path.join(HERE, "lib", "libcsim.so")
+HEADER = os.path.join(ROOT, "include", "csim.h")
+
+DIRICHLET, NEUMANN, PERIODIC = 0, 1, 2
+LEFT, RIGHT, BOTTOM, TOP = 0, 1, 2, 3
+NO_NEIGHBOR = -1
+UNIQUE_ID_BYTES = 128
+VARIANTS = {"auto": 0, "dpp": 1, "lds": 2, "naive": 3}
+
+_BC_NAMES = {  # reference src/io.cpp:35-44 bc_from_string aliases
+    "dirichlet": DIRICHLET, "fixed": DIRICHLET,
+    "neumann": NEUMANN, "noflux": NEUMANN, "zero-flux": NEUMANN,
+    "periodic": PERIODIC, "period": PERIODIC,
+}
+
+
+class CsimError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"csim error {code}: {msg}")
+        self.code = code
+
+
+class Decomp(C.Structure):
+    """struct csim_decomp == reference Decomp2D without the communicator."""
+    _fields_ = [("size", C.c_int), ("rank", C.c_int), ("dims", C.c_int * 2),
+                ("coords", C.c_int * 2), ("nbr", C.c_int * 4),
+                ("nx_global", C.c_int), ("ny_global", C.c_int),
+                ("nx_local", C.c_int), ("ny_local", C.c_int),
+                ("x_offset", C.c_int), ("y_offset", C.c_int)]
+
+    def as_dict(self):
+        return dict(dims0=self.dims[0], dims1=self.dims[1], cx=self.coords[0], cy=self.coords[1],
+                    left=self.nbr[0], right=self.nbr[1], down=self.nbr[2], up=self.nbr[3],
+                    nx_local=self.nx_local, ny_local=self.ny_local, x_offset=self.x_offset,
+                    y_offset=self.y_offset)
+
+
+def build(force: bool = False) -> str:
+    """Compile csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force or not os.path.exists(LIB_PATH):
+        args = ["make", "-s", "-C", os.path.join(HERE, "csrc")]
+        if force:
+            args.append("-B")
+        subprocess.run(args, check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load lib/libcsim.so and declare every prototype of include/csim.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            f"{LIB_PATH} is missing: run __graft_entry__.build() (there is no CPU fallback)")
+    if os.environ.get("CSIM_PRELOAD_TORCH", "1") != "0":
+        # torch bundles its own ROCm runtime (libamdhip64.so.7 / librccl.so.1); importing it first
+        # makes libcsim.so resolve to that same copy, so a process never holds two HIP runtimes.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
+    d, i = C.c_double, C.c_int
+    sig = {
+        "csim_last_error": (C.c_char_p, []),
+        "csim_abi_version": (i, []),
+        "csim_device_count": (i, [ip]),
+        "csim_set_device": (i, [i]),
+        "csim_device_name": (i, [C.c_char_p, C.c_size_t]),
+        "csim_safe_dt": (d, [d] * 5),
+        "csim_decomp_init": (i, [i, i, i, i, C.POINTER(Decomp)]),
+        "csim_field_create": (i, [i, i, i, d, d, C.POINTER(vp)]),
+        "csim_field_destroy": (i, [vp]),
+        "csim_field_upload": (i, [vp, dp]),
+        "csim_field_download": (i, [vp, dp]),
+        "csim_field_download_interior": (i, [vp, dp]),
+        "csim_field_fill": (i, [vp, d]),
+        "csim_field_copy": (i, [vp, vp]),
+        "csim_field_swap": (i, [vp, vp]),
+        "csim_field_minmax": (i, [vp, dp]),
+        "csim_field_sum": (i, [vp, dp]),
+        "csim_field_linf_diff": (i, [vp, vp, dp]),
+        "csim_apply_boundary": (i, [vp, ip, ip, d]),
+        "csim_diffusion_step": (i, [vp, vp, d, d]),
+        "csim_advection_step": (i, [vp, vp, d, d, d]),
+        "csim_fused_step": (i, [vp, vp, d, d, d, d]),
+        "csim_stepper_create": (i, [C.POINTER(Decomp), d, d, ip, d, C.POINTER(vp)]),
+        "csim_stepper_destroy": (i, [vp]),
+        "csim_comm_unique_id": (i, [vp, C.c_size_t]),
+        "csim_stepper_comm_init": (i, [vp, vp, C.c_size_t]),
+        "csim_stepper_upload": (i, [vp, dp]),
+        "csim_stepper_download": (i, [vp, dp]),
+        "csim_stepper_download_interior": (i, [vp, dp]),
+        "csim_stepper_init_gaussian": (i, [vp, d, d, d, d]),
+        "csim_stepper_exchange_halos": (i, [vp]),
+        "csim_stepper_run": (i, [vp, d, d, d, d, i]),
+        "csim_stepper_sync": (i, [vp]),
+        "csim_stepper_minmax": (i, [vp, dp]),
+        "csim_stepper_sum": (i, [vp, dp]),
+        "csim_stepper_set_option": (i, [vp, C.c_char_p, C.c_long]),
+        "csim_stepper_kernel_time": (i, [vp, dp, C.POINTER(C.c_long)]),
+        "csim_stepper_reset_timers": (i, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+EXPORTS = None  # filled lazily by declared_symbols()
+
+
+def declared_symbols():
+    """Every function name declared in include/csim.h (parsed from the header text)."""
+    import re
+    txt = open(HEADER).read()
+    return sorted(set(re.findall(r"\b(csim_[a-z0-9_]+)\s*\(", txt)))
+
+
+def _ck(rc):
+    if rc != 0:
+        raise CsimError(rc, lib().csim_last_error().decode())
+
+
+def _dp(a):
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _i4(v):
+    return (C.c_int * 4)(*[int(x) for x in v])
+
+
+def bc_from_string(s: str) -> int:
+    try:
+        return _BC_NAMES[s.lower()]
+    except KeyError:
+        raise RuntimeError("Unknown BC type: " + s)
+
+
+def bc_codes(code: str):
+    """'dnpd' -> [left, right, bottom, top]."""
+    m = {"d": DIRICHLET, "n": NEUMANN, "p": PERIODIC}
+    return [m[c] for c in code.lower()]
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    _ck(lib().csim_device_count(C.byref(n)))
+    return n.value
+
+
+def set_device(dev: int) -> None:
+    _ck(lib().csim_set_device(dev))
+
+
+def device_name() -> str:
+    buf = C.create_string_buffer(256)
+    _ck(lib().csim_device_name(buf, 256))
+    return buf.value.decode()
+
+
+def safe_dt(dx, dy, vx, vy, D) -> float:
+    return lib().csim_safe_dt(dx, dy, vx, vy, D)
+
+
+def decomp_init(size, rank, nx_global, ny_global) -> Decomp:
+    d = Decomp()
+    _ck(lib().csim_decomp_init(size, rank, nx_global, ny_global, C.byref(d)))
+    return d
+
+
+class Field:
+    """Device mirror of the reference `struct Field` (include/field.hpp:5-21)."""
+
+    def __init__(self, nx, ny, halo=1, dx=1.0, dy=1.0):
+        self.nx_local, self.ny_local, self.halo, self.dx, self.dy = nx, ny, halo, dx, dy
+        h = C.c_void_p()
+        _ck(lib().csim_field_create(nx, ny, halo, dx, dy, C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().csim_field_destroy(self._h)
+            self._h = None
+
+    def nx_total(self):
+        return self.nx_local + 2 * self.halo
+
+    def ny_total(self):
+        return self.ny_local + 2 * self.halo
+
+    def upload(self, host: np.ndarray):
+        assert host.shape == (self.ny_total(), self.nx_total())
+        _ck(lib().csim_field_upload(self._h, _dp(np.ascontiguousarray(host, dtype=np.float64))))
+        return self
+
+    def download(self) -> np.ndarray:
+        out = np.empty((self.ny_total(), self.nx_total()))
+        _ck(lib().csim_field_download(self._h, _dp(out)))
+        return out
+
+    def download_interior(self) -> np.ndarray:
+        out = np.empty((self.ny_local, self.nx_local))
+        _ck(lib().csim_field_download_interior(self._h, _dp(out)))
+        return out
+
+    def fill(self, v):
+        _ck(lib().csim_field_fill(self._h, v))
+
+    def copy_from(self, other: "Field"):
+        _ck(lib().csim_field_copy(self._h, other._h))
+
+    def swap(self, other: "Field"):
+        _ck(lib().csim_field_swap(self._h, other._h))
+
+    def minmax(self):
+        o = (C.c_double * 2)()
+        _ck(lib().csim_field_minmax(self._h, o))
+        return o[0], o[1]
+
+    def sum(self):
+        o = C.c_double()
+        _ck(lib().csim_field_sum(self._h, C.byref(o)))
+        return o.value
+
+    def linf_diff(self, other: "Field"):
+        o = C.c_double()
+        _ck(lib().csim_field_linf_diff(self._h, other._h, C.byref(o)))
+        return o.value
+
+
+def apply_boundary(f: Field, bc, is_physical=(1, 1, 1, 1), value=0.0):
+    _ck(lib().csim_apply_boundary(f._h, _i4(bc), _i4(is_physical), value))
+
+
+def diffusion_step(u: Field, out: Field, D, dt):
+    _ck(lib().csim_diffusion_step(u._h, out._h, D, dt))
+
+
+def advection_step(u: Field, out: Field, vx, vy, dt):
+    _ck(lib().csim_advection_step(u._h, out._h, vx, vy, dt))
+
+
+def fused_step(u: Field, out: Field, D, dt, vx, vy):
+    _ck(lib().csim_fused_step(u._h, out._h, D, dt, vx, vy))
+
+
+def comm_unique_id() -> bytes:
+    buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+    _ck(lib().csim_comm_unique_id(buf, UNIQUE_ID_BYTES))
+    return buf.raw
+
+
+class Stepper:
+    """The time loop of reference src/main.cpp:93-118 (minus I/O) on one GPU / one rank."""
+
+    def __init__(self, dec: Decomp, dx=1.0, dy=1.0, bc=(0, 0, 0, 0), bc_value=0.0):
+        self.dec = dec
+        self.nx, self.ny = dec.nx_local, dec.ny_local
+        h = C.c_void_p()
+        _ck(lib().csim_stepper_create(C.byref(dec), dx, dy, _i4(bc), bc_value, C.byref(h)))
+        self._h = h
+
+    @classmethod
+    def single(cls, nx, ny, dx=1.0, dy=1.0, bc=(0, 0, 0, 0), bc_value=0.0):
+        return cls(decomp_init(1, 0, nx, ny), dx, dy, bc, bc_value)
+
+    def __del__(self):
+        self.close()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().csim_stepper_destroy(self._h)
+            self._h = None
+
+    def comm_init(self, unique_id: bytes):
+        buf = C.create_string_buffer(unique_id, UNIQUE_ID_BYTES)
+        _ck(lib().csim_stepper_comm_init(self._h, buf, UNIQUE_ID_BYTES))
+
+    def upload(self, host: np.ndarray):
+        assert host.shape == (self.ny + 2, self.nx + 2)
+        _ck(lib().csim_stepper_upload(self._h, _dp(np.ascontiguousarray(host, dtype=np.float64))))
+
+    def download(self) -> np.ndarray:
+        out = np.empty((self.ny + 2, self.nx + 2))
+        _ck(lib().csim_stepper_download(self._h, _dp(out)))
+        return out
+
+    def download_interior(self) -> np.ndarray:
+        out = np.empty((self.ny, self.nx))
+        _ck(lib().csim_stepper_download_interior(self._h, _dp(out)))
+        return out
+
+    def init_gaussian(self, A=1.0, sigma_frac=0.05, xc_frac=0.5, yc_frac=0.5):
+        _ck(lib().csim_stepper_init_gaussian(self._h, A, sigma_frac, xc_frac, yc_frac))
+
+    def exchange_halos(self):
+        _ck(lib().csim_stepper_exchange_halos(self._h))
+
+    def run(self, D, dt, vx, vy, nsteps):
+        _ck(lib().csim_stepper_run(self._h, D, dt, vx, vy, nsteps))
+
+    def sync(self):
+        _ck(lib().csim_stepper_sync(self._h))
+
+    def minmax(self):
+        o = (C.c_double * 2)()
+        _ck(lib().csim_stepper_minmax(self._h, o))
+        return o[0], o[1]
+
+    def sum(self):
+        o = C.c_double()
+        _ck(lib().csim_stepper_sum(self._h, C.byref(o)))
+        return o.value
+
+    def set_option(self, key: str, value: int):
+        _ck(lib().csim_stepper_set_option(self._h, key.encode(), int(value)))
+
+    def kernel_time(self):
+        ms, n = C.c_double(), C.c_long()
+        _ck(lib().csim_stepper_kernel_time(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def reset_timers(self):
+        _ck(lib().csim_stepper_reset_timers(self._h))

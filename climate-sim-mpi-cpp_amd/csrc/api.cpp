@@ -1,0 +1,661 @@
+// api.cpp — the C ABI of include/csim.h: device Field mirror, the reference-granularity
+// operators, MPI-free decomposition, and the time-loop stepper with its RCCL halo exchange.
+// Compiled with hipcc; host code only (kernels live in kernels.hip).
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#include "internal.hpp"
+
+namespace csim {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define CSIM_NCCL(expr)                                                                        \
+    do {                                                                                       \
+        ncclResult_t r_ = (expr);                                                              \
+        if (r_ != ncclSuccess)                                                                 \
+            return ::csim::fail(CSIM_ERR_RCCL, std::string(#expr) + ": " + ncclGetErrorString(r_)); \
+    } while (0)
+
+#define CSIM_REQUIRE(cond, msg) \
+    do {                        \
+        if (!(cond)) return ::csim::fail(CSIM_ERR_ARG, msg); \
+    } while (0)
+
+static bool pow2(double x) {
+    if (!(x > 0.0) || !std::isnormal(x)) return false;
+    int e = 0;
+    return std::frexp(x, &e) == 0.5 && std::isnormal(1.0 / x);
+}
+
+Phys make_phys(double dx, double dy, double D, double dt, double vx, double vy) {
+    Phys p;
+    p.kdiff = dt * D;
+    p.mdt = -dt;
+    p.vx = vx;
+    p.vy = vy;
+    p.dx = dx;
+    p.dy = dy;
+    p.dx2 = dx * dx;
+    p.dy2 = dy * dy;
+    p.rdx = 1.0 / dx;
+    p.rdy = 1.0 / dy;
+    p.rdx2 = 1.0 / p.dx2;
+    p.rdy2 = 1.0 / p.dy2;
+    if (dx == 1.0 && dy == 1.0)
+        p.div_mode = 0;
+    else if (pow2(dx) && pow2(dy) && pow2(p.dx2) && pow2(p.dy2))
+        p.div_mode = 1;
+    else
+        p.div_mode = 2;
+    return p;
+}
+
+static int finish_partials(const double* scratch_dev, int nblocks, int kind, double out[2],
+                           hipStream_t st) {
+    std::vector<double> h(2 * REDUCE_BLOCKS);
+    CSIM_HIP(hipMemcpyAsync(h.data(), scratch_dev, sizeof(double) * 2 * REDUCE_BLOCKS,
+                            hipMemcpyDeviceToHost, st));
+    CSIM_HIP(hipStreamSynchronize(st));
+    double r0 = h[0], r1 = h[REDUCE_BLOCKS];
+    for (int k = 1; k < nblocks; ++k) {
+        if (kind == 0) {
+            r0 = std::fmin(r0, h[k]);
+            r1 = std::fmax(r1, h[REDUCE_BLOCKS + k]);
+        } else if (kind == 1) {
+            r0 += h[k];
+        } else {
+            r0 = std::fmax(r0, h[k]);
+        }
+    }
+    out[0] = r0;
+    out[1] = r1;
+    return CSIM_OK;
+}
+
+static int reduce_blocks(int nrows) { return nrows < REDUCE_BLOCKS ? nrows : REDUCE_BLOCKS; }
+
+static int upload_2d(double* d, int nx, int ny, int pitch, const double* host) {
+    CSIM_HIP(hipMemcpy2D(d + (LPAD - 1), sizeof(double) * pitch, host, sizeof(double) * (nx + 2),
+                         sizeof(double) * (nx + 2), ny + 2, hipMemcpyHostToDevice));
+    return CSIM_OK;
+}
+static int download_2d(const double* d, int nx, int ny, int pitch, double* host) {
+    CSIM_HIP(hipMemcpy2D(host, sizeof(double) * (nx + 2), d + (LPAD - 1), sizeof(double) * pitch,
+                         sizeof(double) * (nx + 2), ny + 2, hipMemcpyDeviceToHost));
+    return CSIM_OK;
+}
+static int download_interior_2d(const double* d, int nx, int ny, int pitch, double* host) {
+    CSIM_HIP(hipMemcpy2D(host, sizeof(double) * nx, d + pitch + LPAD, sizeof(double) * pitch,
+                         sizeof(double) * nx, ny, hipMemcpyDeviceToHost));
+    return CSIM_OK;
+}
+
+}  // namespace csim
+
+using namespace csim;
+
+// ---- stepper handle ----------------------------------------------------------------------------
+struct csim_stepper {
+    csim_decomp dec{};
+    double dx = 1.0, dy = 1.0;
+    int bc[4]{0, 0, 0, 0};
+    int phys[4]{1, 1, 1, 1};
+    double bc_value = 0.0;
+    int nx = 0, ny = 0, pitch = 0;
+    double* cur = nullptr;
+    double* nxt = nullptr;
+    double* scratch = nullptr;
+    double* send[4]{nullptr, nullptr, nullptr, nullptr};
+    double* recv[4]{nullptr, nullptr, nullptr, nullptr};
+    hipStream_t s_comp = nullptr, s_comm = nullptr;
+    hipEvent_t ev_edge = nullptr, ev_recv = nullptr;
+    ncclComm_t comm = nullptr;
+    bool multi = false;       // has at least one neighbour
+    bool halo_fresh = false;  // recv[] holds the neighbours' edge lines of `cur`
+    SweepCfg cfg;
+    int overlap = 1;
+    int profile = 0;
+    std::vector<hipEvent_t> ev_pool;  // start/stop pairs around sweep launches
+    size_t ev_used = 0;
+    double prof_ms = 0.0;
+    long prof_launches = 0;
+    size_t bytes() const { return sizeof(double) * static_cast<size_t>(ny + 2) * pitch; }
+};
+
+extern "C" {
+
+const char* csim_last_error(void) { return g_err.c_str(); }
+int csim_abi_version(void) { return CSIM_ABI_VERSION; }
+
+int csim_device_count(int* count) {
+    CSIM_REQUIRE(count, "count is null");
+    CSIM_HIP(hipGetDeviceCount(count));
+    return CSIM_OK;
+}
+int csim_set_device(int device) {
+    CSIM_HIP(hipSetDevice(device));
+    return CSIM_OK;
+}
+int csim_device_name(char* buf, size_t n) {
+    CSIM_REQUIRE(buf && n > 0, "bad buffer");
+    int dev = 0;
+    CSIM_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    CSIM_HIP(hipGetDeviceProperties(&prop, dev));
+    std::snprintf(buf, n, "%s", prop.gcnArchName);
+    return CSIM_OK;
+}
+
+// reference include/stability.hpp:5-16
+double csim_safe_dt(double dx, double dy, double vx, double vy, double D) {
+    const double inf = std::numeric_limits<double>::infinity();
+    const double ax = std::fabs(vx), ay = std::fabs(vy);
+    const double rate = (ax > 0 ? ax / dx : 0.0) + (ay > 0 ? ay / dy : 0.0);
+    const double dt_adv = rate > 0 ? 1.0 / rate : inf;
+    const double w = 1.0 / (dx * dx) + 1.0 / (dy * dy);
+    const double dt_diff = D > 0 ? 1.0 / (2.0 * D * w) : inf;
+    return std::min(dt_adv, dt_diff);
+}
+
+// reference src/decomp.cpp:5-34 with MPI_Dims_create / MPI_Cart_* re-derived:
+// most balanced factor pair, larger factor first; rank = coords[0]*dims[1] + coords[1].
+int csim_decomp_init(int size, int rank, int nx_global, int ny_global, csim_decomp* out) {
+    CSIM_REQUIRE(out, "out is null");
+    CSIM_REQUIRE(size >= 1 && rank >= 0 && rank < size, "bad size/rank");
+    CSIM_REQUIRE(nx_global > 0 && ny_global > 0, "nx/ny must be > 0");
+    int small = 1;
+    for (int f = 1; static_cast<long>(f) * f <= size; ++f)
+        if (size % f == 0) small = f;
+    csim_decomp d{};
+    d.size = size;
+    d.rank = rank;
+    d.dims[0] = size / small;
+    d.dims[1] = small;
+    d.coords[0] = rank / d.dims[1];
+    d.coords[1] = rank % d.dims[1];
+    const int cx = d.coords[0], cy = d.coords[1];
+    d.nbr[CSIM_LEFT] = cx > 0 ? (cx - 1) * d.dims[1] + cy : CSIM_NO_NEIGHBOR;
+    d.nbr[CSIM_RIGHT] = cx + 1 < d.dims[0] ? (cx + 1) * d.dims[1] + cy : CSIM_NO_NEIGHBOR;
+    d.nbr[CSIM_BOTTOM] = cy > 0 ? cx * d.dims[1] + (cy - 1) : CSIM_NO_NEIGHBOR;
+    d.nbr[CSIM_TOP] = cy + 1 < d.dims[1] ? cx * d.dims[1] + (cy + 1) : CSIM_NO_NEIGHBOR;
+    d.nx_global = nx_global;
+    d.ny_global = ny_global;
+    const int bx = nx_global / d.dims[0], by = ny_global / d.dims[1];
+    d.nx_local = bx + (cx == d.dims[0] - 1 ? nx_global % d.dims[0] : 0);
+    d.ny_local = by + (cy == d.dims[1] - 1 ? ny_global % d.dims[1] : 0);
+    d.x_offset = cx * bx;
+    d.y_offset = cy * by;
+    CSIM_REQUIRE(d.nx_local > 0 && d.ny_local > 0, "more ranks than cells along an axis");
+    *out = d;
+    return CSIM_OK;
+}
+
+// ---- Field -------------------------------------------------------------------------------------
+int csim_field_create(int nx, int ny, int halo, double dx, double dy, csim_field** out) {
+    CSIM_REQUIRE(out, "out is null");
+    *out = nullptr;
+    CSIM_REQUIRE(nx > 0 && ny > 0, "nx/ny must be > 0");
+    CSIM_REQUIRE(halo == 1, "only halo == 1 is supported (reference src/main.cpp:65)");
+    CSIM_REQUIRE(dx > 0 && dy > 0, "dx/dy must be > 0");
+    csim_field* f = new csim_field;
+    f->nx = nx;
+    f->ny = ny;
+    f->halo = halo;
+    f->dx = dx;
+    f->dy = dy;
+    f->pitch = pitch_for(nx);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&f->d), f->bytes());
+    if (e == hipSuccess) e = hipMemset(f->d, 0, f->bytes());
+    if (e == hipSuccess)
+        e = hipMalloc(reinterpret_cast<void**>(&f->scratch), sizeof(double) * 2 * REDUCE_BLOCKS);
+    if (e != hipSuccess) {
+        if (f->d) (void)hipFree(f->d);
+        delete f;
+        return fail(CSIM_ERR_HIP, std::string("csim_field_create: ") + hipGetErrorString(e));
+    }
+    *out = f;
+    return CSIM_OK;
+}
+
+int csim_field_destroy(csim_field* f) {
+    if (!f) return CSIM_OK;
+    if (f->d) (void)hipFree(f->d);
+    if (f->scratch) (void)hipFree(f->scratch);
+    delete f;
+    return CSIM_OK;
+}
+
+int csim_field_upload(csim_field* f, const double* host) {
+    CSIM_REQUIRE(f && host, "null argument");
+    return upload_2d(f->d, f->nx, f->ny, f->pitch, host);
+}
+int csim_field_download(const csim_field* f, double* host) {
+    CSIM_REQUIRE(f && host, "null argument");
+    return download_2d(f->d, f->nx, f->ny, f->pitch, host);
+}
+int csim_field_download_interior(const csim_field* f, double* host) {
+    CSIM_REQUIRE(f && host, "null argument");
+    return download_interior_2d(f->d, f->nx, f->ny, f->pitch, host);
+}
+
+int csim_field_fill(csim_field* f, double value) {
+    CSIM_REQUIRE(f, "null field");
+    CSIM_HIP(launch_fill(f->d, f->nx, f->ny, f->pitch, value, nullptr));
+    CSIM_HIP(hipStreamSynchronize(nullptr));
+    return CSIM_OK;
+}
+
+static bool same_shape(const csim_field* a, const csim_field* b) {
+    return a && b && a->nx == b->nx && a->ny == b->ny;
+}
+
+int csim_field_copy(csim_field* dst, const csim_field* src) {
+    CSIM_REQUIRE(same_shape(dst, src), "fields differ in shape");
+    CSIM_HIP(hipMemcpy(dst->d, src->d, src->bytes(), hipMemcpyDeviceToDevice));
+    return CSIM_OK;
+}
+
+int csim_field_swap(csim_field* a, csim_field* b) {
+    CSIM_REQUIRE(same_shape(a, b), "fields differ in shape");
+    std::swap(a->d, b->d);
+    return CSIM_OK;
+}
+
+int csim_field_minmax(const csim_field* f, double out[2]) {
+    CSIM_REQUIRE(f && out, "null argument");
+    CSIM_HIP(launch_minmax(f->d, f->nx, f->ny, f->pitch, f->scratch, nullptr));
+    return finish_partials(f->scratch, reduce_blocks(f->ny + 2), 0, out, nullptr);
+}
+int csim_field_sum(const csim_field* f, double* out) {
+    CSIM_REQUIRE(f && out, "null argument");
+    double r[2];
+    CSIM_HIP(launch_sum(f->d, f->nx, f->ny, f->pitch, f->scratch, nullptr));
+    int rc = finish_partials(f->scratch, reduce_blocks(f->ny), 1, r, nullptr);
+    *out = r[0];
+    return rc;
+}
+int csim_field_linf_diff(const csim_field* a, const csim_field* b, double* out) {
+    CSIM_REQUIRE(same_shape(a, b) && out, "fields differ in shape");
+    double r[2];
+    CSIM_HIP(launch_linf(a->d, b->d, a->nx, a->ny, a->pitch, a->scratch, nullptr));
+    int rc = finish_partials(a->scratch, reduce_blocks(a->ny), 2, r, nullptr);
+    *out = r[0];
+    return rc;
+}
+
+// ---- operators ----------------------------------------------------------------------------------
+static bool valid_bc(const int bc[4]) {
+    for (int s = 0; s < 4; ++s)
+        if (bc[s] < CSIM_BC_DIRICHLET || bc[s] > CSIM_BC_PERIODIC) return false;
+    return true;
+}
+
+int csim_apply_boundary(csim_field* f, const int bc[4], const int is_physical[4], double value) {
+    CSIM_REQUIRE(f && bc && is_physical, "null argument");
+    CSIM_REQUIRE(valid_bc(bc), "unknown boundary type");
+    GhostArgs g{};
+    for (int s = 0; s < 4; ++s) {
+        g.bc[s] = bc[s];
+        g.phys[s] = is_physical[s] != 0;
+        g.recv[s] = nullptr;
+    }
+    g.value = value;
+    CSIM_HIP(launch_ghost_fill(f->d, nullptr, f->nx, f->ny, f->pitch, g, nullptr));
+    CSIM_HIP(hipStreamSynchronize(nullptr));
+    return CSIM_OK;
+}
+
+int csim_diffusion_step(const csim_field* u, csim_field* out, double D, double dt) {
+    CSIM_REQUIRE(same_shape(u, out), "fields differ in shape");
+    CSIM_REQUIRE(u->d != out->d, "u and out must be distinct fields");
+    const Phys p = make_phys(u->dx, u->dy, D, dt, 0.0, 0.0);
+    CSIM_HIP(launch_diffusion_only(u->d, out->d, u->nx, u->ny, u->pitch, p, nullptr));
+    CSIM_HIP(launch_ring_copy(u->d, out->d, u->nx, u->ny, u->pitch, nullptr));
+    CSIM_HIP(hipStreamSynchronize(nullptr));
+    return CSIM_OK;
+}
+
+int csim_advection_step(const csim_field* u, csim_field* out, double vx, double vy, double dt) {
+    CSIM_REQUIRE(same_shape(u, out), "fields differ in shape");
+    CSIM_REQUIRE(u->d != out->d, "u and out must be distinct fields");
+    const Phys p = make_phys(u->dx, u->dy, 0.0, dt, vx, vy);
+    CSIM_HIP(launch_advection_only(u->d, out->d, u->nx, u->ny, u->pitch, p, nullptr));
+    CSIM_HIP(hipStreamSynchronize(nullptr));
+    return CSIM_OK;
+}
+
+int csim_fused_step(const csim_field* u, csim_field* out, double D, double dt, double vx, double vy) {
+    CSIM_REQUIRE(same_shape(u, out), "fields differ in shape");
+    CSIM_REQUIRE(u->d != out->d, "u and out must be distinct fields");
+    const Phys p = make_phys(u->dx, u->dy, D, dt, vx, vy);
+    SweepCfg cfg;
+    CSIM_HIP(launch_ring_copy(u->d, out->d, u->nx, u->ny, u->pitch, nullptr));
+    CSIM_HIP(launch_sweep(u->d, out->d, u->nx, u->ny, u->pitch, p, cfg, nullptr));
+    CSIM_HIP(hipStreamSynchronize(nullptr));
+    return CSIM_OK;
+}
+
+// ---- stepper -------------------------------------------------------------------------------------
+int csim_stepper_create(const csim_decomp* dec, double dx, double dy, const int bc[4],
+                        double bc_value, csim_stepper** out) {
+    CSIM_REQUIRE(out, "out is null");
+    *out = nullptr;
+    CSIM_REQUIRE(dec && bc, "null argument");
+    CSIM_REQUIRE(dec->nx_local > 0 && dec->ny_local > 0, "empty local tile");
+    CSIM_REQUIRE(dx > 0 && dy > 0, "dx/dy must be > 0");
+    CSIM_REQUIRE(valid_bc(bc), "unknown boundary type");
+    csim_stepper* s = new csim_stepper;
+    s->dec = *dec;
+    s->dx = dx;
+    s->dy = dy;
+    s->bc_value = bc_value;
+    s->nx = dec->nx_local;
+    s->ny = dec->ny_local;
+    s->pitch = pitch_for(s->nx);
+    for (int k = 0; k < 4; ++k) {
+        s->bc[k] = bc[k];
+        s->phys[k] = dec->nbr[k] < 0;
+        if (!s->phys[k]) s->multi = true;
+    }
+    hipError_t e = hipSuccess;
+    auto ok = [&](hipError_t r) {
+        if (e == hipSuccess) e = r;
+        return e == hipSuccess;
+    };
+    ok(hipMalloc(reinterpret_cast<void**>(&s->cur), s->bytes())) &&
+        ok(hipMalloc(reinterpret_cast<void**>(&s->nxt), s->bytes())) &&
+        ok(hipMemset(s->cur, 0, s->bytes())) && ok(hipMemset(s->nxt, 0, s->bytes())) &&
+        ok(hipMalloc(reinterpret_cast<void**>(&s->scratch), sizeof(double) * 2 * REDUCE_BLOCKS)) &&
+        ok(hipStreamCreateWithFlags(&s->s_comp, hipStreamNonBlocking)) &&
+        ok(hipStreamCreateWithFlags(&s->s_comm, hipStreamNonBlocking)) &&
+        ok(hipEventCreateWithFlags(&s->ev_edge, hipEventDisableTiming)) &&
+        ok(hipEventCreateWithFlags(&s->ev_recv, hipEventDisableTiming));
+    for (int k = 0; k < 4 && e == hipSuccess; ++k) {
+        if (s->phys[k]) continue;
+        const size_t n = sizeof(double) * static_cast<size_t>(k < 2 ? s->ny : s->nx);
+        ok(hipMalloc(reinterpret_cast<void**>(&s->send[k]), n)) &&
+            ok(hipMalloc(reinterpret_cast<void**>(&s->recv[k]), n)) &&
+            ok(hipMemset(s->send[k], 0, n)) && ok(hipMemset(s->recv[k], 0, n));
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        csim_stepper_destroy(s);
+        return fail(CSIM_ERR_HIP, std::string("csim_stepper_create: ") + hipGetErrorString(e));
+    }
+    *out = s;
+    return CSIM_OK;
+}
+
+int csim_stepper_destroy(csim_stepper* s) {
+    if (!s) return CSIM_OK;
+    if (s->s_comp) (void)hipStreamSynchronize(s->s_comp);
+    if (s->s_comm) (void)hipStreamSynchronize(s->s_comm);
+    if (s->comm) (void)ncclCommDestroy(s->comm);
+    for (hipEvent_t ev : s->ev_pool) (void)hipEventDestroy(ev);
+    for (int k = 0; k < 4; ++k) {
+        if (s->send[k]) (void)hipFree(s->send[k]);
+        if (s->recv[k]) (void)hipFree(s->recv[k]);
+    }
+    if (s->ev_edge) (void)hipEventDestroy(s->ev_edge);
+    if (s->ev_recv) (void)hipEventDestroy(s->ev_recv);
+    if (s->s_comp) (void)hipStreamDestroy(s->s_comp);
+    if (s->s_comm) (void)hipStreamDestroy(s->s_comm);
+    if (s->cur) (void)hipFree(s->cur);
+    if (s->nxt) (void)hipFree(s->nxt);
+    if (s->scratch) (void)hipFree(s->scratch);
+    delete s;
+    return CSIM_OK;
+}
+
+int csim_comm_unique_id(void* id, size_t nbytes) {
+    static_assert(sizeof(ncclUniqueId) == CSIM_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    CSIM_REQUIRE(id && nbytes >= sizeof(ncclUniqueId), "id buffer too small");
+    ncclUniqueId u;
+    CSIM_NCCL(ncclGetUniqueId(&u));
+    std::memcpy(id, &u, sizeof(u));
+    return CSIM_OK;
+}
+
+int csim_stepper_comm_init(csim_stepper* s, const void* id, size_t nbytes) {
+    CSIM_REQUIRE(s && id && nbytes >= sizeof(ncclUniqueId), "bad argument");
+    if (s->comm) return fail(CSIM_ERR_STATE, "communicator already initialised");
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof(u));
+    CSIM_NCCL(ncclCommInitRank(&s->comm, s->dec.size, u, s->dec.rank));
+    return CSIM_OK;
+}
+
+int csim_stepper_upload(csim_stepper* s, const double* host) {
+    CSIM_REQUIRE(s && host, "null argument");
+    CSIM_HIP(hipStreamSynchronize(s->s_comp));
+    CSIM_HIP(hipStreamSynchronize(s->s_comm));
+    int rc = upload_2d(s->cur, s->nx, s->ny, s->pitch, host);
+    if (rc) return rc;
+    // both ping-pong buffers start with the same ghost ring (reference main.cpp:104 copies u->tmp)
+    CSIM_HIP(hipMemcpy(s->nxt, s->cur, s->bytes(), hipMemcpyDeviceToDevice));
+    s->halo_fresh = false;
+    return CSIM_OK;
+}
+
+int csim_stepper_download(csim_stepper* s, double* host) {
+    CSIM_REQUIRE(s && host, "null argument");
+    CSIM_HIP(hipStreamSynchronize(s->s_comp));
+    return download_2d(s->cur, s->nx, s->ny, s->pitch, host);
+}
+
+int csim_stepper_download_interior(csim_stepper* s, double* host) {
+    CSIM_REQUIRE(s && host, "null argument");
+    CSIM_HIP(hipStreamSynchronize(s->s_comp));
+    return download_interior_2d(s->cur, s->nx, s->ny, s->pitch, host);
+}
+
+int csim_stepper_init_gaussian(csim_stepper* s, double A, double sigma_frac, double xc_frac,
+                               double yc_frac) {
+    CSIM_REQUIRE(s, "null stepper");
+    CSIM_HIP(hipStreamSynchronize(s->s_comm));
+    CSIM_HIP(hipMemsetAsync(s->cur, 0, s->bytes(), s->s_comp));
+    CSIM_HIP(launch_gaussian(s->cur, s->nx, s->ny, s->pitch, s->dec.x_offset, s->dec.y_offset,
+                             s->dec.nx_global, s->dec.ny_global, s->dx, s->dy, A, sigma_frac,
+                             xc_frac, yc_frac, s->s_comp));
+    CSIM_HIP(hipMemcpyAsync(s->nxt, s->cur, s->bytes(), hipMemcpyDeviceToDevice, s->s_comp));
+    CSIM_HIP(hipStreamSynchronize(s->s_comp));
+    s->halo_fresh = false;
+    return CSIM_OK;
+}
+
+// one grouped RCCL exchange of the staged edge lines (replaces the ≤8 MPI requests of reference
+// src/halo.cpp:28-46).  Sends are posted left,right,bottom,top and receives right,left,top,bottom
+// so that message order also matches when both x- (or y-) neighbours are the same peer.
+static int post_exchange(csim_stepper* s, hipStream_t st) {
+    if (!s->comm) return fail(CSIM_ERR_STATE, "halo exchange needs csim_stepper_comm_init first");
+    static const int recv_order[4] = {CSIM_RIGHT, CSIM_LEFT, CSIM_TOP, CSIM_BOTTOM};
+    CSIM_NCCL(ncclGroupStart());
+    for (int k = 0; k < 4; ++k) {
+        if (s->phys[k]) continue;
+        const size_t n = static_cast<size_t>(k < 2 ? s->ny : s->nx);
+        CSIM_NCCL(ncclSend(s->send[k], n, ncclDouble, s->dec.nbr[k], s->comm, st));
+    }
+    for (int q = 0; q < 4; ++q) {
+        const int k = recv_order[q];
+        if (s->phys[k]) continue;
+        const size_t n = static_cast<size_t>(k < 2 ? s->ny : s->nx);
+        CSIM_NCCL(ncclRecv(s->recv[k], n, ncclDouble, s->dec.nbr[k], s->comm, st));
+    }
+    CSIM_NCCL(ncclGroupEnd());
+    return CSIM_OK;
+}
+
+// halos of the CURRENT field: pack its edge lines, exchange, leave them staged in recv[]
+static int refresh_halos(csim_stepper* s) {
+    CSIM_HIP(launch_pack(s->cur, s->nx, s->ny, s->pitch, s->send, s->s_comp));
+    int rc = post_exchange(s, s->s_comp);
+    if (rc) return rc;
+    s->halo_fresh = true;
+    return CSIM_OK;
+}
+
+static GhostArgs ghost_args(const csim_stepper* s) {
+    GhostArgs g{};
+    for (int k = 0; k < 4; ++k) {
+        g.bc[k] = s->bc[k];
+        g.phys[k] = s->phys[k];
+        g.recv[k] = s->phys[k] ? nullptr : s->recv[k];
+    }
+    g.value = s->bc_value;
+    return g;
+}
+
+int csim_stepper_exchange_halos(csim_stepper* s) {
+    CSIM_REQUIRE(s, "null stepper");
+    if (!s->multi) return CSIM_OK;
+    int rc = refresh_halos(s);
+    if (rc) return rc;
+    // unpack only (no boundary rule): physical sides are left alone, like reference halo.cpp
+    GhostArgs g = ghost_args(s);
+    for (int k = 0; k < 4; ++k)
+        if (g.phys[k]) g.bc[k] = CSIM_BC_PERIODIC;
+    CSIM_HIP(launch_ghost_fill(s->cur, s->nxt, s->nx, s->ny, s->pitch, g, s->s_comp));
+    CSIM_HIP(hipStreamSynchronize(s->s_comp));
+    return CSIM_OK;
+}
+
+static int prof_fold(csim_stepper* s) {
+    if (s->ev_used == 0) return CSIM_OK;
+    CSIM_HIP(hipStreamSynchronize(s->s_comp));
+    for (size_t k = 0; k + 1 < s->ev_used; k += 2) {
+        float ms = 0.f;
+        CSIM_HIP(hipEventElapsedTime(&ms, s->ev_pool[k], s->ev_pool[k + 1]));
+        s->prof_ms += ms;
+        s->prof_launches += 1;
+    }
+    s->ev_used = 0;
+    return CSIM_OK;
+}
+
+int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy, int nsteps) {
+    CSIM_REQUIRE(s, "null stepper");
+    CSIM_REQUIRE(nsteps >= 0, "nsteps must be >= 0");
+    if (s->multi && !s->comm)
+        return fail(CSIM_ERR_STATE, "multi-rank stepper needs csim_stepper_comm_init before run");
+    const Phys p = make_phys(s->dx, s->dy, D, dt, vx, vy);
+    const GhostArgs g = ghost_args(s);
+    constexpr size_t POOL = 2048;
+    for (int n = 0; n < nsteps; ++n) {
+        if (s->multi) {
+            if (!s->halo_fresh) {
+                int rc = refresh_halos(s);  // on s_comp: ordered before the ghost fill
+                if (rc) return rc;
+            } else if (s->overlap) {
+                CSIM_HIP(hipStreamWaitEvent(s->s_comp, s->ev_recv, 0));
+            }
+        }
+        // exchange_halos (unpack) + apply_boundary, mirrored into the partner buffer
+        CSIM_HIP(launch_ghost_fill(s->cur, s->nxt, s->nx, s->ny, s->pitch, g, s->s_comp));
+        if (s->multi && s->overlap) {
+            // edge lines of the NEXT field first, so their exchange overlaps the full sweep
+            CSIM_HIP(launch_edge_pack(s->cur, s->nx, s->ny, s->pitch, p, s->send, s->s_comp));
+            CSIM_HIP(hipEventRecord(s->ev_edge, s->s_comp));
+            CSIM_HIP(hipStreamWaitEvent(s->s_comm, s->ev_edge, 0));
+            int rc = post_exchange(s, s->s_comm);
+            if (rc) return rc;
+            CSIM_HIP(hipEventRecord(s->ev_recv, s->s_comm));
+        }
+        if (s->profile) {
+            if (s->ev_used + 2 > POOL) {
+                int rc = prof_fold(s);
+                if (rc) return rc;
+            }
+            while (s->ev_pool.size() < s->ev_used + 2) {
+                hipEvent_t ev;
+                CSIM_HIP(hipEventCreate(&ev));
+                s->ev_pool.push_back(ev);
+            }
+            CSIM_HIP(hipEventRecord(s->ev_pool[s->ev_used], s->s_comp));
+        }
+        CSIM_HIP(launch_sweep(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, s->cfg, s->s_comp));
+        if (s->profile) {
+            CSIM_HIP(hipEventRecord(s->ev_pool[s->ev_used + 1], s->s_comp));
+            s->ev_used += 2;
+        }
+        std::swap(s->cur, s->nxt);
+        if (s->multi && !s->overlap) s->halo_fresh = false;  // serial mode: re-exchange next step
+    }
+    return CSIM_OK;
+}
+
+int csim_stepper_sync(csim_stepper* s) {
+    CSIM_REQUIRE(s, "null stepper");
+    CSIM_HIP(hipStreamSynchronize(s->s_comp));
+    CSIM_HIP(hipStreamSynchronize(s->s_comm));
+    return CSIM_OK;
+}
+
+int csim_stepper_minmax(csim_stepper* s, double out[2]) {
+    CSIM_REQUIRE(s && out, "null argument");
+    CSIM_HIP(launch_minmax(s->cur, s->nx, s->ny, s->pitch, s->scratch, s->s_comp));
+    return finish_partials(s->scratch, reduce_blocks(s->ny + 2), 0, out, s->s_comp);
+}
+
+int csim_stepper_sum(csim_stepper* s, double* out) {
+    CSIM_REQUIRE(s && out, "null argument");
+    double r[2];
+    CSIM_HIP(launch_sum(s->cur, s->nx, s->ny, s->pitch, s->scratch, s->s_comp));
+    int rc = finish_partials(s->scratch, reduce_blocks(s->ny), 1, r, s->s_comp);
+    *out = r[0];
+    return rc;
+}
+
+int csim_stepper_set_option(csim_stepper* s, const char* key, long value) {
+    CSIM_REQUIRE(s && key, "null argument");
+    const std::string k(key);
+    if (k == "variant") {
+        CSIM_REQUIRE(value >= VAR_AUTO && value <= VAR_NAIVE, "unknown variant");
+        s->cfg.variant = static_cast<int>(value);
+    } else if (k == "rows_per_chunk") {
+        CSIM_REQUIRE(value >= 0, "rows_per_chunk must be >= 0");
+        s->cfg.rows_per_chunk = static_cast<int>(value);
+    } else if (k == "prefetch") {
+        CSIM_REQUIRE(value >= 0 && value <= 8, "prefetch must be 0..8");
+        s->cfg.prefetch = static_cast<int>(value);
+    } else if (k == "xcd_swizzle") {
+        s->cfg.xcd_swizzle = value != 0;
+    } else if (k == "overlap") {
+        s->overlap = value != 0;
+    } else if (k == "profile") {
+        s->profile = value != 0;
+    } else {
+        return fail(CSIM_ERR_ARG, "unknown option: " + k);
+    }
+    return CSIM_OK;
+}
+
+int csim_stepper_kernel_time(csim_stepper* s, double* total_ms, long* launches) {
+    CSIM_REQUIRE(s && total_ms && launches, "null argument");
+    int rc = prof_fold(s);
+    if (rc) return rc;
+    *total_ms = s->prof_ms;
+    *launches = s->prof_launches;
+    return CSIM_OK;
+}
+
+int csim_stepper_reset_timers(csim_stepper* s) {
+    CSIM_REQUIRE(s, "null stepper");
+    int rc = prof_fold(s);
+    if (rc) return rc;
+    s->prof_ms = 0.0;
+    s->prof_launches = 0;
+    return CSIM_OK;
+}
+
+}  // extern "C"

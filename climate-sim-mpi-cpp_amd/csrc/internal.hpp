@@ -1,0 +1,112 @@
+// internal.hpp — shared declarations of the HIP engine behind include/csim.h.
+//
+// Device layout of a Field (MI355X-first, not the host layout): rows are padded to a pitch
+// so that the FIRST INTERIOR column (i = 1) of every row starts on a 128-byte boundary and a
+// 64-lane wavefront reading 2 doubles per lane covers exactly 8 full 128-byte lines:
+//
+//     element (i, j), 0 <= i <= nx+1, 0 <= j <= ny+1   ->   base[j * pitch + (LPAD - 1) + i]
+//
+//     | 15 unused | ghost i=0 | interior i=1..nx (128-B aligned) | ghost i=nx+1 | pad ... |
+//
+// pitch = LPAD + round_up(nx + 1, 128) + 16 doubles; for nx = 16384 that is 16544 doubles =
+// 132352 B, an odd multiple of 256 B, so vertically adjacent rows do not alias onto one HBM
+// channel.  Pads are zero and never written.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdio>
+#include <string>
+
+#include "csim.h"
+
+namespace csim {
+
+constexpr int LPAD = 16;        // doubles in front of the first interior column
+constexpr int WAVE_COLS = 128;  // columns one wavefront covers per row (64 lanes x 2 doubles)
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+inline int pitch_for(int nx) { return LPAD + round_up(nx + 1, WAVE_COLS) + 16; }
+
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+#define CSIM_HIP(expr)                                                                       \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return ::csim::fail(CSIM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// physics constants of one sweep, precomputed on the host exactly as the reference forms them
+struct Phys {
+    double kdiff;  // dt * D            (reference src/diffusion.cpp:15  "dt * D * lap")
+    double mdt;    // -dt               (reference src/advection.cpp:31  "(-dt) * adv")
+    double vx, vy;
+    double dx, dy;      // divisors of the upwind differences
+    double dx2, dy2;    // dx*dx, dy*dy: divisors of the second differences
+    double rdx, rdy, rdx2, rdy2;  // exact reciprocals (only used when all four are powers of two)
+    int div_mode;       // 0: dx == dy == 1 (x/1 is x)   1: exact reciprocal multiply   2: IEEE divide
+};
+Phys make_phys(double dx, double dy, double D, double dt, double vx, double vy);
+
+// kernel variants of the fused sweep (option "variant")
+enum { VAR_AUTO = 0, VAR_DPP = 1, VAR_LDS = 2, VAR_NAIVE = 3 };
+
+struct SweepCfg {
+    int variant = VAR_AUTO;
+    int rows_per_chunk = 0;  // 0 = auto
+    int prefetch = 0;        // 0 = auto (rows kept in flight per wavefront)
+    int xcd_swizzle = 1;
+};
+
+// ---- kernel launchers (kernels.hip) --------------------------------------------------------
+// All pointers are device pointers in the padded layout above.
+hipError_t launch_sweep(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
+                        const SweepCfg& cfg, hipStream_t st);
+hipError_t launch_diffusion_only(const double* in, double* out, int nx, int ny, int pitch,
+                                 const Phys& p, hipStream_t st);
+hipError_t launch_advection_only(const double* in, double* out, int nx, int ny, int pitch,
+                                 const Phys& p, hipStream_t st);
+hipError_t launch_ring_copy(const double* in, double* out, int nx, int ny, int pitch, hipStream_t st);
+hipError_t launch_fill(double* f, int nx, int ny, int pitch, double v, hipStream_t st);
+
+struct GhostArgs {
+    int bc[4];
+    int phys[4];          // side is a physical edge (no neighbour)
+    double value;
+    const double* recv[4];  // per side: staged halo from the neighbour (nullptr on physical sides)
+};
+// boundary fill (+ unpack of received halos) written to `a` and, when b != nullptr, to `b` too
+hipError_t launch_ghost_fill(double* a, double* b, int nx, int ny, int pitch, const GhostArgs& g,
+                             hipStream_t st);
+// updated values of the four edge lines of the NEXT field, computed from `in` and written
+// straight into the send staging buffers (nullptr = side not needed)
+hipError_t launch_edge_pack(const double* in, int nx, int ny, int pitch, const Phys& p,
+                            double* const send[4], hipStream_t st);
+// plain pack of the current edge lines (used by csim_stepper_exchange_halos)
+hipError_t launch_pack(const double* in, int nx, int ny, int pitch, double* const send[4],
+                       hipStream_t st);
+hipError_t launch_gaussian(double* f, int nx, int ny, int pitch, int x_off, int y_off, int nxg,
+                           int nyg, double dx, double dy, double A, double sigma_frac,
+                           double xc_frac, double yc_frac, hipStream_t st);
+
+// reductions: partial results per block in `scratch` (>= 2 * REDUCE_BLOCKS doubles), finished on host
+constexpr int REDUCE_BLOCKS = 1024;
+hipError_t launch_minmax(const double* f, int nx, int ny, int pitch, double* scratch, hipStream_t st);
+hipError_t launch_sum(const double* f, int nx, int ny, int pitch, double* scratch, hipStream_t st);
+hipError_t launch_linf(const double* a, const double* b, int nx, int ny, int pitch, double* scratch,
+                       hipStream_t st);
+
+}  // namespace csim
+
+// ---- opaque handle types -------------------------------------------------------------------
+struct csim_field {
+    int nx = 0, ny = 0, halo = 1;
+    double dx = 1.0, dy = 1.0;
+    int pitch = 0;
+    double* d = nullptr;        // (ny + 2) * pitch doubles
+    double* scratch = nullptr;  // reduction partials
+    size_t bytes() const { return sizeof(double) * static_cast<size_t>(ny + 2) * pitch; }
+};

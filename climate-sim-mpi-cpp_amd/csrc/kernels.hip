@@ -1,0 +1,665 @@
+// kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the advection–diffusion hot path.
+//
+// The path is HBM-bandwidth-bound (16 algorithmic bytes and ~15 fp64 flops per cell update),
+// so there is no MFMA here; the rules that matter are 16-byte-per-lane coalesced row accesses
+// on 128-byte-aligned rows, one HBM read and one HBM write per cell (vertical reuse in
+// registers while a wavefront marches up its column strip, horizontal reuse through
+// cross-lane DPP moves or an LDS-staged row), enough row loads in flight per wavefront to
+// cover HBM latency, and an XCD-aware block->tile map so strip/chunk neighbours share an L2.
+//
+// Arithmetic follows the reference's association order exactly (reference
+// src/diffusion.cpp:9-16, src/advection.cpp:13-33) and this file is compiled with
+// -ffp-contract=off, so every kernel is bit-identical to the reference CPU path.
+#include "internal.hpp"
+
+#pragma clang fp contract(off)
+
+namespace csim {
+
+// -------------------------------------------------------------------------------------------
+// per-cell update:  o = c + (dt*D)*lap;  o = o + (-dt)*(vx*dudx + vy*dudy)
+//   lap  = ((E - 2c) + W)/(dx*dx) + ((N - 2c) + S)/(dy*dy)
+//   dudx = vx >= 0 ? (c - W)/dx : (E - c)/dx      (dudy likewise)
+// DIV 0: dx == dy == 1, x/1 == x.  DIV 1: all divisors are powers of two, so x * (1/d) is the
+// correctly rounded quotient too (bit-identical to x/d).  DIV 2: true IEEE fp64 division.
+// -------------------------------------------------------------------------------------------
+template <int DIV>
+__device__ __forceinline__ double diffuse_term(double c, double W, double E, double S, double N,
+                                               const Phys& p) {
+    const double tc = 2.0 * c;
+    double lx = (E - tc) + W;
+    double ly = (N - tc) + S;
+    if (DIV == 1) {
+        lx = lx * p.rdx2;
+        ly = ly * p.rdy2;
+    } else if (DIV == 2) {
+        lx = lx / p.dx2;
+        ly = ly / p.dy2;
+    }
+    const double lap = lx + ly;
+    return c + p.kdiff * lap;
+}
+
+template <int DIV>
+__device__ __forceinline__ double advect_term(double c, double W, double E, double S, double N,
+                                              const Phys& p) {
+    double gx = (p.vx >= 0.0) ? (c - W) : (E - c);
+    double gy = (p.vy >= 0.0) ? (c - S) : (N - c);
+    if (DIV == 1) {
+        gx = gx * p.rdx;
+        gy = gy * p.rdy;
+    } else if (DIV == 2) {
+        gx = gx / p.dx;
+        gy = gy / p.dy;
+    }
+    const double adv = p.vx * gx + p.vy * gy;
+    return p.mdt * adv;
+}
+
+template <int DIV>
+__device__ __forceinline__ double cell(double c, double W, double E, double S, double N,
+                                       const Phys& p) {
+    const double o = diffuse_term<DIV>(c, W, E, S, N, p);
+    return o + advect_term<DIV>(c, W, E, S, N, p);
+}
+
+// ---- cross-lane neighbour moves (DPP, no LDS traffic) ---------------------------------------
+// wave_shr:1  lane i <- lane i-1, lane 0 keeps `edge`;  wave_shl:1  lane i <- lane i+1, lane 63
+// keeps `edge` (bound_ctrl off: lanes without a source keep the old value).
+__device__ __forceinline__ double from_prev_lane(double src, double edge) {
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(src), 0x138, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(src), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double from_next_lane(double src, double edge) {
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(src), 0x130, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(src), 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// Blocks b and b+8 share an XCD (round-robin dispatch), so give every XCD one contiguous run of
+// tile ids: x-adjacent strips and y-adjacent chunks then hit the same 4 MiB L2.  Bijective for
+// any grid size.  Placement only affects speed, never results.
+__device__ __forceinline__ int xcd_remap(int b, int nb, int enable) {
+    if (!enable || nb < 16) return b;
+    const int per = nb >> 3, rem = nb & 7;
+    const int xcd = b & 7, q = b >> 3;
+    return xcd < rem ? xcd * (per + 1) + q : rem * (per + 1) + (xcd - rem) * per + q;
+}
+
+__device__ __forceinline__ void store_pair(double* dst, double ox, double oy, int nvalid) {
+    if (nvalid >= 2) {
+        *reinterpret_cast<double2*>(dst) = make_double2(ox, oy);
+    } else if (nvalid == 1) {
+        dst[0] = ox;
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// VAR_DPP — the default fused sweep.
+// One wavefront owns a strip of 128 interior columns (2 per lane, one 16-byte load per lane
+// per row = 8 full 128-byte lines per wave) and marches up `ry` rows keeping rows j-1, j, j+1
+// of its own columns in registers, with PF further rows already in flight.  W/E neighbours
+// come from the adjacent lanes by DPP; only lane 0 / lane 63 fetch the one column outside the
+// strip (an L1/L2 hit: the neighbouring wave streams that line at the same time).  No LDS, no
+// barriers, ~40 VGPRs -> 8 waves/SIMD.  HBM traffic per cell: 8 B read (+2/ry halo rows) + 8 B
+// written.
+// -------------------------------------------------------------------------------------------
+template <int DIV, int PF>
+__global__ __launch_bounds__(256) void k_sweep_dpp(const double* __restrict__ in,
+                                                   double* __restrict__ out, int nx, int ny,
+                                                   int pitch, int ry, int nwgx, int swz, Phys p) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int lin = xcd_remap(blockIdx.x, gridDim.x, swz);
+    const int wgx = lin % nwgx, chunk = lin / nwgx;
+    const int c0 = (wgx * 4 + wave) * WAVE_COLS;
+    if (c0 >= nx) return;  // wave-uniform
+    const int jb = chunk * ry + 1;
+    const int je = min(jb + ry - 1, ny);
+    const int col = c0 + 2 * lane;
+    const int nvalid = nx - col;
+    const size_t xoff = static_cast<size_t>(LPAD + col);
+    const bool edge_lane = (lane == 0) || (lane == 63);
+    const size_t eoff = static_cast<size_t>(LPAD + c0 + (lane == 0 ? -1 : WAVE_COLS));
+
+    auto ld2 = [&](int j) {
+        return *reinterpret_cast<const double2*>(in + static_cast<size_t>(j) * pitch + xoff);
+    };
+    auto lde = [&](int j) {
+        double e = 0.0;
+        if (edge_lane) e = in[static_cast<size_t>(j) * pitch + eoff];
+        return e;
+    };
+
+    double2 S = ld2(jb - 1);
+    double2 C = ld2(jb);
+    double eC = lde(jb);
+    double2 q[PF];
+    double eq[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        q[u] = make_double2(0.0, 0.0);
+        eq[u] = 0.0;
+        const int r = jb + 1 + u;
+        if (r <= je + 1) {
+            q[u] = ld2(r);
+            eq[u] = lde(r);
+        }
+    }
+    for (int j = jb; j <= je; j += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int jj = j + u;
+            if (jj <= je) {  // wave-uniform
+                const double2 N = q[u];
+                const double eN = eq[u];
+                const int r = jj + 1 + PF;
+                if (r <= je + 1) {
+                    q[u] = ld2(r);
+                    eq[u] = lde(r);
+                }
+                const double Wx = from_prev_lane(C.y, eC);
+                const double Ey = from_next_lane(C.x, eC);
+                const double ox = cell<DIV>(C.x, Wx, C.y, S.x, N.x, p);
+                const double oy = cell<DIV>(C.y, C.x, Ey, S.y, N.y, p);
+                store_pair(out + static_cast<size_t>(jj) * pitch + xoff, ox, oy, nvalid);
+                S = C;
+                C = N;
+                eC = eN;
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// VAR_LDS — LDS-staged marching sweep.  A 256-thread workgroup owns a 512-column strip; every
+// row is loaded once (16 B per lane), staged in a double-buffered LDS row (ds_write_b128) with
+// its two halo columns, and the W/E neighbours are read back from LDS (ds_read_b64); N/S stay
+// in registers.  One workgroup barrier per row.
+// LDS row layout (doubles): [1] = left halo, [2 .. 513] = strip, [514] = right halo.
+// -------------------------------------------------------------------------------------------
+constexpr int LDS_STRIP = 512;
+template <int DIV>
+__global__ __launch_bounds__(256) void k_sweep_lds(const double* __restrict__ in,
+                                                   double* __restrict__ out, int nx, int ny,
+                                                   int pitch, int ry, int nwgx, int swz, Phys p) {
+    __shared__ __attribute__((aligned(16))) double rows[2][LDS_STRIP + 8];
+    const int tid = threadIdx.x;
+    const int lin = xcd_remap(blockIdx.x, gridDim.x, swz);
+    const int wgx = lin % nwgx, chunk = lin / nwgx;
+    const int c0 = wgx * LDS_STRIP;
+    const int jb = chunk * ry + 1;
+    const int je = min(jb + ry - 1, ny);
+    const int col = c0 + 2 * tid;
+    const int nvalid = nx - col;
+    const size_t xoff = static_cast<size_t>(LPAD + col);
+    const bool have = (LPAD + col + 1) < pitch;
+    const bool halo_lane = (tid == 0) || (tid == 255);
+    const size_t hoff = static_cast<size_t>(tid == 0 ? LPAD + c0 - 1 : LPAD + min(c0 + LDS_STRIP, nx));
+    const int hidx = tid == 0 ? 1 : LDS_STRIP + 2;
+
+    auto ld2 = [&](int j) {
+        double2 v = make_double2(0.0, 0.0);
+        if (have) v = *reinterpret_cast<const double2*>(in + static_cast<size_t>(j) * pitch + xoff);
+        return v;
+    };
+    auto ldh = [&](int j) {
+        double e = 0.0;
+        if (halo_lane) e = in[static_cast<size_t>(j) * pitch + hoff];
+        return e;
+    };
+
+    double2 S = ld2(jb - 1);
+    double2 C = ld2(jb);
+    {
+        const double h = ldh(jb);
+        *reinterpret_cast<double2*>(&rows[jb & 1][2 + 2 * tid]) = C;
+        if (halo_lane) rows[jb & 1][hidx] = h;
+    }
+    __syncthreads();
+    for (int j = jb; j <= je; ++j) {
+        const double2 N = ld2(j + 1);
+        const double hN = ldh(j + 1);
+        const double* cur = rows[j & 1];
+        const double Wx = cur[1 + 2 * tid];
+        const double Ey = cur[4 + 2 * tid];
+        double* nxt = rows[(j + 1) & 1];
+        *reinterpret_cast<double2*>(&nxt[2 + 2 * tid]) = N;
+        if (halo_lane) nxt[hidx] = hN;
+        const double ox = cell<DIV>(C.x, Wx, C.y, S.x, N.x, p);
+        const double oy = cell<DIV>(C.y, C.x, Ey, S.y, N.y, p);
+        store_pair(out + static_cast<size_t>(j) * pitch + xoff, ox, oy, nvalid);
+        S = C;
+        C = N;
+        __syncthreads();
+    }
+}
+
+// VAR_NAIVE — one thread per cell pair, all five points straight from global memory (cache
+// reuse only).  Kept as the measured baseline the tuned variants are compared against.
+template <int DIV>
+__global__ __launch_bounds__(256) void k_sweep_naive(const double* __restrict__ in,
+                                                     double* __restrict__ out, int nx, int ny,
+                                                     int pitch, Phys p) {
+    const int col = (blockIdx.x * 256 + threadIdx.x) * 2;
+    const int j = blockIdx.y + 1;
+    if (col >= nx) return;
+    const size_t o = static_cast<size_t>(j) * pitch + LPAD + col;
+    const double2 C = *reinterpret_cast<const double2*>(in + o);
+    const double2 N = *reinterpret_cast<const double2*>(in + o + pitch);
+    const double2 S = *reinterpret_cast<const double2*>(in + o - pitch);
+    const double W = in[o - 1];
+    const double E = in[o + 2];
+    const double ox = cell<DIV>(C.x, W, C.y, S.x, N.x, p);
+    const double oy = cell<DIV>(C.y, C.x, E, S.y, N.y, p);
+    store_pair(out + o, ox, oy, nx - col);
+}
+
+// ---- operators at the reference's own granularity (not the hot path) ------------------------
+// MODE 0: out = diffusion(u) on the interior (reference src/diffusion.cpp:9-16)
+// MODE 1: out += advection(u)               (reference src/advection.cpp:13-33)
+template <int DIV, int MODE>
+__global__ __launch_bounds__(256) void k_unit_op(const double* __restrict__ in,
+                                                 double* __restrict__ out, int nx, int ny,
+                                                 int pitch, Phys p) {
+    const int i = blockIdx.x * 256 + threadIdx.x + 1;
+    const int j = blockIdx.y + 1;
+    if (i > nx) return;
+    const size_t o = static_cast<size_t>(j) * pitch + (LPAD - 1) + i;
+    const double c = in[o], W = in[o - 1], E = in[o + 1], S = in[o - pitch], N = in[o + pitch];
+    if (MODE == 0)
+        out[o] = diffuse_term<DIV>(c, W, E, S, N, p);
+    else
+        out[o] = out[o] + advect_term<DIV>(c, W, E, S, N, p);
+}
+
+// outer ring of `in` copied to `out` (reference src/diffusion.cpp:18-25)
+__global__ void k_ring_copy(const double* __restrict__ in, double* __restrict__ out, int nx, int ny,
+                            int pitch) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nxt = nx + 2, nyt = ny + 2;
+    if (t < nxt) {
+        const size_t a = static_cast<size_t>(LPAD - 1 + t);
+        out[a] = in[a];
+        const size_t b = static_cast<size_t>(nyt - 1) * pitch + a;
+        out[b] = in[b];
+    }
+    if (t < nyt) {
+        const size_t a = static_cast<size_t>(t) * pitch + (LPAD - 1);
+        out[a] = in[a];
+        out[a + nxt - 1] = in[a + nxt - 1];
+    }
+}
+
+__global__ void k_fill(double* __restrict__ f, int nx, int ny, int pitch, double v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (i < nx + 2) f[static_cast<size_t>(j) * pitch + (LPAD - 1) + i] = v;
+}
+
+// -------------------------------------------------------------------------------------------
+// Ghost fill = unpack of the staged neighbour halos (reference src/halo.cpp:28-43) followed by
+// apply_boundary (reference src/boundary.cpp:12-54) in ONE launch, written to the current
+// field and, when `b` is given, identically to the ping-pong partner so that after the sweep
+// and swap the new field carries the same ghost ring the reference gets from its copy
+// (src/main.cpp:104) + ring copy (src/diffusion.cpp:18-25).
+// The reference fills sides sequentially (left, right, bottom, top), which only matters at the
+// four corners; they are evaluated functionally by one thread from values no other thread of
+// this launch writes.
+// -------------------------------------------------------------------------------------------
+struct GhostDev {
+    int bc[4];
+    int phys[4];
+    double value;
+    const double* recv[4];
+};
+
+__device__ __forceinline__ size_t at(int i, int j, int pitch) {
+    return static_cast<size_t>(j) * pitch + (LPAD - 1) + i;
+}
+
+__global__ __launch_bounds__(256) void k_ghost_fill(double* __restrict__ a, double* __restrict__ b,
+                                                    int nx, int ny, int pitch, GhostDev g) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    auto put = [&](size_t o, double v) {
+        a[o] = v;
+        if (b) b[o] = v;
+    };
+    if (t < ny) {  // ghost columns at row j = t + 1
+        const int j = t + 1;
+        for (int s = CSIM_LEFT; s <= CSIM_RIGHT; ++s) {
+            const int ig = s == CSIM_LEFT ? 0 : nx + 1;
+            const int ia = s == CSIM_LEFT ? 1 : nx;
+            if (g.phys[s]) {
+                if (g.bc[s] == CSIM_BC_DIRICHLET)
+                    put(at(ig, j, pitch), g.value);
+                else if (g.bc[s] == CSIM_BC_NEUMANN)
+                    put(at(ig, j, pitch), a[at(ia, j, pitch)]);
+            } else if (g.recv[s]) {
+                put(at(ig, j, pitch), g.recv[s][t]);
+            }
+        }
+    }
+    if (t < nx) {  // ghost rows at column i = t + 1
+        const int i = t + 1;
+        for (int s = CSIM_BOTTOM; s <= CSIM_TOP; ++s) {
+            const int jg = s == CSIM_BOTTOM ? 0 : ny + 1;
+            const int ja = s == CSIM_BOTTOM ? 1 : ny;
+            if (g.phys[s]) {
+                if (g.bc[s] == CSIM_BC_DIRICHLET)
+                    put(at(i, jg, pitch), g.value);
+                else if (g.bc[s] == CSIM_BC_NEUMANN)
+                    put(at(i, jg, pitch), a[at(i, ja, pitch)]);
+            } else if (g.recv[s]) {
+                put(at(i, jg, pitch), g.recv[s][t]);
+            }
+        }
+    }
+    const int tc = nx > ny ? nx : ny;
+    if (t == tc) {  // the four corners
+        for (int cs = CSIM_LEFT; cs <= CSIM_RIGHT; ++cs) {
+            const int ig = cs == CSIM_LEFT ? 0 : nx + 1;
+            const int ia = cs == CSIM_LEFT ? 1 : nx;
+            for (int rs = CSIM_BOTTOM; rs <= CSIM_TOP; ++rs) {
+                const int jg = rs == CSIM_BOTTOM ? 0 : ny + 1;
+                const int ja = rs == CSIM_BOTTOM ? 1 : ny;
+                const bool row_d = g.phys[rs] && g.bc[rs] == CSIM_BC_DIRICHLET;
+                const bool row_n = g.phys[rs] && g.bc[rs] == CSIM_BC_NEUMANN;
+                const bool col_d = g.phys[cs] && g.bc[cs] == CSIM_BC_DIRICHLET;
+                const bool col_n = g.phys[cs] && g.bc[cs] == CSIM_BC_NEUMANN;
+                if (row_d) {
+                    put(at(ig, jg, pitch), g.value);
+                } else if (row_n) {
+                    // row rule copies the already column-filled ghost cell (ig, ja)
+                    double v;
+                    if (col_d)
+                        v = g.value;
+                    else if (col_n)
+                        v = a[at(ia, ja, pitch)];
+                    else if (!g.phys[cs] && g.recv[cs])
+                        v = g.recv[cs][ja - 1];
+                    else
+                        v = a[at(ig, ja, pitch)];
+                    put(at(ig, jg, pitch), v);
+                } else if (col_d) {
+                    put(at(ig, jg, pitch), g.value);
+                } else if (col_n) {
+                    // column rule copies ghost-row cell (ia, jg): stable (periodic) or just received
+                    double v;
+                    if (!g.phys[rs] && g.recv[rs])
+                        v = g.recv[rs][ia - 1];
+                    else
+                        v = a[at(ia, jg, pitch)];
+                    put(at(ig, jg, pitch), v);
+                }
+            }
+        }
+    }
+}
+
+// The four edge lines of the NEXT field, computed from the current one and written directly
+// into the send staging buffers, so the RCCL exchange can start before (and overlap with) the
+// full sweep.  Same arithmetic as the sweep => the values sent equal the values later stored.
+template <int DIV>
+__global__ __launch_bounds__(256) void k_edge_pack(const double* __restrict__ in, int nx, int ny,
+                                                   int pitch, Phys p, double* sl, double* sr,
+                                                   double* sb, double* st) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    auto upd = [&](int i, int j) {
+        const size_t o = at(i, j, pitch);
+        return cell<DIV>(in[o], in[o - 1], in[o + 1], in[o - pitch], in[o + pitch], p);
+    };
+    if (t < ny) {
+        if (sl) sl[t] = upd(1, t + 1);
+        if (sr) sr[t] = upd(nx, t + 1);
+    }
+    if (t < nx) {
+        if (sb) sb[t] = upd(t + 1, 1);
+        if (st) st[t] = upd(t + 1, ny);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pack(const double* __restrict__ in, int nx, int ny, int pitch,
+                                              double* sl, double* sr, double* sb, double* st) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < ny) {
+        if (sl) sl[t] = in[at(1, t + 1, pitch)];
+        if (sr) sr[t] = in[at(nx, t + 1, pitch)];
+    }
+    if (t < nx) {
+        if (sb) sb[t] = in[at(t + 1, 1, pitch)];
+        if (st) st[t] = in[at(t + 1, ny, pitch)];
+    }
+}
+
+// gaussian hotspot on the device (reference src/init.cpp:12-33); exp() may differ from glibc
+// in the last ulp, so parity runs upload a host-made field instead.
+__global__ __launch_bounds__(256) void k_gaussian(double* __restrict__ f, int nx, int ny, int pitch,
+                                                  int x_off, int y_off, double dx, double dy,
+                                                  double A, double xc, double yc, double sig) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int j = blockIdx.y;
+    if (i >= nx) return;
+    const double x = (x_off + i + 0.5) * dx;
+    const double y = (y_off + j + 0.5) * dy;
+    const double r2 = (x - xc) * (x - xc) + (y - yc) * (y - yc);
+    f[at(i + 1, j + 1, pitch)] = A * exp(-r2 / (2.0 * sig * sig));
+}
+
+// ---- wavefront-level reductions --------------------------------------------------------------
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmin(v, __shfl_xor(v, m, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = v + __shfl_xor(v, m, 64);
+    return v;
+}
+
+// KIND 0: min/max over i0..i1, j0..j1 ; KIND 1: sum ; KIND 2: max |a-b|
+template <int KIND>
+__global__ __launch_bounds__(256) void k_reduce(const double* __restrict__ a,
+                                                const double* __restrict__ b, int i0, int i1,
+                                                int j0, int j1, int pitch,
+                                                double* __restrict__ partial) {
+    __shared__ double sh[2][4];
+    double r0 = KIND == 0 ? INFINITY : 0.0;  // min | sum | linf
+    double r1 = -INFINITY;                   // max
+    for (int j = j0 + blockIdx.x; j <= j1; j += gridDim.x) {
+        for (int i = i0 + threadIdx.x; i <= i1; i += 256) {
+            const size_t o = at(i, j, pitch);
+            const double v = a[o];
+            if (KIND == 0) {
+                r0 = fmin(r0, v);
+                r1 = fmax(r1, v);
+            } else if (KIND == 1) {
+                r0 = r0 + v;
+            } else {
+                r0 = fmax(r0, fabs(v - b[o]));
+            }
+        }
+    }
+    if (KIND == 0) {
+        r0 = wave_min(r0);
+        r1 = wave_max(r1);
+    } else if (KIND == 1) {
+        r0 = wave_sum(r0);
+    } else {
+        r0 = wave_max(r0);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        sh[0][wave] = r0;
+        sh[1][wave] = r1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double x0 = sh[0][0], x1 = sh[1][0];
+        for (int w = 1; w < 4; ++w) {
+            if (KIND == 0) {
+                x0 = fmin(x0, sh[0][w]);
+                x1 = fmax(x1, sh[1][w]);
+            } else if (KIND == 1) {
+                x0 = x0 + sh[0][w];
+            } else {
+                x0 = fmax(x0, sh[0][w]);
+            }
+        }
+        partial[blockIdx.x] = x0;
+        partial[REDUCE_BLOCKS + blockIdx.x] = x1;
+    }
+}
+
+// ============================================================================================
+// launchers
+// ============================================================================================
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+template <int DIV>
+static hipError_t sweep_div(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
+                            const SweepCfg& cfg, hipStream_t st) {
+    int variant = cfg.variant == VAR_AUTO ? VAR_DPP : cfg.variant;
+    int ry = cfg.rows_per_chunk > 0 ? cfg.rows_per_chunk : 64;
+    if (ry > ny) ry = ny;
+    const int nchunks = cdiv(ny, ry);
+    if (variant == VAR_NAIVE) {
+        dim3 grid(cdiv(nx, 512), ny);
+        hipLaunchKernelGGL(k_sweep_naive<DIV>, grid, dim3(256), 0, st, in, out, nx, ny, pitch, p);
+    } else if (variant == VAR_LDS) {
+        const int nwgx = cdiv(nx, LDS_STRIP);
+        hipLaunchKernelGGL(k_sweep_lds<DIV>, dim3(nwgx * nchunks), dim3(256), 0, st, in, out, nx, ny,
+                           pitch, ry, nwgx, cfg.xcd_swizzle, p);
+    } else {
+        const int nwgx = cdiv(cdiv(nx, WAVE_COLS), 4);
+        const dim3 grid(nwgx * nchunks);
+        const int pf = cfg.prefetch > 0 ? cfg.prefetch : 2;
+        if (pf <= 1)
+            hipLaunchKernelGGL((k_sweep_dpp<DIV, 1>), grid, dim3(256), 0, st, in, out, nx, ny, pitch,
+                               ry, nwgx, cfg.xcd_swizzle, p);
+        else if (pf == 2)
+            hipLaunchKernelGGL((k_sweep_dpp<DIV, 2>), grid, dim3(256), 0, st, in, out, nx, ny, pitch,
+                               ry, nwgx, cfg.xcd_swizzle, p);
+        else if (pf <= 4)
+            hipLaunchKernelGGL((k_sweep_dpp<DIV, 4>), grid, dim3(256), 0, st, in, out, nx, ny, pitch,
+                               ry, nwgx, cfg.xcd_swizzle, p);
+        else
+            hipLaunchKernelGGL((k_sweep_dpp<DIV, 8>), grid, dim3(256), 0, st, in, out, nx, ny, pitch,
+                               ry, nwgx, cfg.xcd_swizzle, p);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_sweep(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
+                        const SweepCfg& cfg, hipStream_t st) {
+    switch (p.div_mode) {
+        case 0: return sweep_div<0>(in, out, nx, ny, pitch, p, cfg, st);
+        case 1: return sweep_div<1>(in, out, nx, ny, pitch, p, cfg, st);
+        default: return sweep_div<2>(in, out, nx, ny, pitch, p, cfg, st);
+    }
+}
+
+template <int MODE>
+static hipError_t unit_op(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
+                          hipStream_t st) {
+    dim3 grid(cdiv(nx, 256), ny);
+    switch (p.div_mode) {
+        case 0: hipLaunchKernelGGL((k_unit_op<0, MODE>), grid, dim3(256), 0, st, in, out, nx, ny, pitch, p); break;
+        case 1: hipLaunchKernelGGL((k_unit_op<1, MODE>), grid, dim3(256), 0, st, in, out, nx, ny, pitch, p); break;
+        default: hipLaunchKernelGGL((k_unit_op<2, MODE>), grid, dim3(256), 0, st, in, out, nx, ny, pitch, p); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_diffusion_only(const double* in, double* out, int nx, int ny, int pitch,
+                                 const Phys& p, hipStream_t st) {
+    return unit_op<0>(in, out, nx, ny, pitch, p, st);
+}
+hipError_t launch_advection_only(const double* in, double* out, int nx, int ny, int pitch,
+                                 const Phys& p, hipStream_t st) {
+    return unit_op<1>(in, out, nx, ny, pitch, p, st);
+}
+
+hipError_t launch_ring_copy(const double* in, double* out, int nx, int ny, int pitch, hipStream_t st) {
+    const int n = (nx > ny ? nx : ny) + 2;
+    hipLaunchKernelGGL(k_ring_copy, dim3(cdiv(n, 256)), dim3(256), 0, st, in, out, nx, ny, pitch);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill(double* f, int nx, int ny, int pitch, double v, hipStream_t st) {
+    hipLaunchKernelGGL(k_fill, dim3(cdiv(nx + 2, 256), ny + 2), dim3(256), 0, st, f, nx, ny, pitch, v);
+    return hipGetLastError();
+}
+
+hipError_t launch_ghost_fill(double* a, double* b, int nx, int ny, int pitch, const GhostArgs& g,
+                             hipStream_t st) {
+    GhostDev d;
+    for (int s = 0; s < 4; ++s) {
+        d.bc[s] = g.bc[s];
+        d.phys[s] = g.phys[s];
+        d.recv[s] = g.recv[s];
+    }
+    d.value = g.value;
+    const int n = (nx > ny ? nx : ny) + 1;
+    hipLaunchKernelGGL(k_ghost_fill, dim3(cdiv(n, 256)), dim3(256), 0, st, a, b, nx, ny, pitch, d);
+    return hipGetLastError();
+}
+
+hipError_t launch_edge_pack(const double* in, int nx, int ny, int pitch, const Phys& p,
+                            double* const send[4], hipStream_t st) {
+    const int n = nx > ny ? nx : ny;
+    const dim3 grid(cdiv(n, 256));
+    switch (p.div_mode) {
+        case 0: hipLaunchKernelGGL(k_edge_pack<0>, grid, dim3(256), 0, st, in, nx, ny, pitch, p, send[0], send[1], send[2], send[3]); break;
+        case 1: hipLaunchKernelGGL(k_edge_pack<1>, grid, dim3(256), 0, st, in, nx, ny, pitch, p, send[0], send[1], send[2], send[3]); break;
+        default: hipLaunchKernelGGL(k_edge_pack<2>, grid, dim3(256), 0, st, in, nx, ny, pitch, p, send[0], send[1], send[2], send[3]); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_pack(const double* in, int nx, int ny, int pitch, double* const send[4],
+                       hipStream_t st) {
+    const int n = nx > ny ? nx : ny;
+    hipLaunchKernelGGL(k_pack, dim3(cdiv(n, 256)), dim3(256), 0, st, in, nx, ny, pitch, send[0],
+                       send[1], send[2], send[3]);
+    return hipGetLastError();
+}
+
+hipError_t launch_gaussian(double* f, int nx, int ny, int pitch, int x_off, int y_off, int nxg,
+                           int nyg, double dx, double dy, double A, double sigma_frac,
+                           double xc_frac, double yc_frac, hipStream_t st) {
+    const double Lx = nxg * dx, Ly = nyg * dy;
+    const double xc = xc_frac * Lx, yc = yc_frac * Ly;
+    const double sig = sigma_frac * (Lx < Ly ? Lx : Ly);
+    hipLaunchKernelGGL(k_gaussian, dim3(cdiv(nx, 256), ny), dim3(256), 0, st, f, nx, ny, pitch, x_off,
+                       y_off, dx, dy, A, xc, yc, sig);
+    return hipGetLastError();
+}
+
+static int reduce_grid(int nrows) { return nrows < REDUCE_BLOCKS ? nrows : REDUCE_BLOCKS; }
+
+hipError_t launch_minmax(const double* f, int nx, int ny, int pitch, double* scratch, hipStream_t st) {
+    hipLaunchKernelGGL(k_reduce<0>, dim3(reduce_grid(ny + 2)), dim3(256), 0, st, f, nullptr, 0, nx + 1,
+                       0, ny + 1, pitch, scratch);
+    return hipGetLastError();
+}
+hipError_t launch_sum(const double* f, int nx, int ny, int pitch, double* scratch, hipStream_t st) {
+    hipLaunchKernelGGL(k_reduce<1>, dim3(reduce_grid(ny)), dim3(256), 0, st, f, nullptr, 1, nx, 1, ny,
+                       pitch, scratch);
+    return hipGetLastError();
+}
+hipError_t launch_linf(const double* a, const double* b, int nx, int ny, int pitch, double* scratch,
+                       hipStream_t st) {
+    hipLaunchKernelGGL(k_reduce<2>, dim3(reduce_grid(ny)), dim3(256), 0, st, a, b, 1, nx, 1, ny, pitch,
+                       scratch);
+    return hipGetLastError();
+}
+
+}  // namespace csim

@@ -1,0 +1,138 @@
+/* include/csim.h — C ABI of the MI355X-native advection–diffusion stepper.
+ *
+ * This is the drop-in boundary for ONE hot path of antoniorizzoeng/climate-sim-mpi-cpp:
+ * the per-time-step sequence
+ *     exchange_halos -> apply_boundary -> copy -> diffusion_step -> advection_step -> swap
+ * (reference src/main.cpp:101-109).  The reference has no FFI/plugin layer: its boundary is
+ * the set of C++ free functions and structs in include/{field,decomp,halo,boundary,diffusion,
+ * advection,stability}.hpp.  Each entry point below names the reference interface it replaces.
+ * The C++ mirror of those headers (same names and signatures) lives in include/climate/ and
+ * calls only this ABI.
+ *
+ * Conventions
+ *   - every function returns 0 (CSIM_OK) or a CSIM_ERR_* code; csim_last_error() gives the text
+ *     (thread-local).  No C++ types, no exceptions cross this boundary.
+ *   - host arrays use the reference layout (reference src/field.cpp:20-25): row-major, ghost
+ *     ring included, element (i,j) at host[j*(nx+2*halo)+i], i contiguous.  Only halo==1 is
+ *     supported, like the reference driver (src/main.cpp:65); other values give CSIM_ERR_ARG.
+ *   - sides are ordered left(x-), right(x+), bottom(y-), top(y+) everywhere.
+ *   - all arithmetic is IEEE fp64 in the reference's association order with no FMA
+ *     contraction, so results are bit-identical to the reference CPU path.
+ *   - there is NO CPU fallback: without a usable gfx950 device the calls fail with CSIM_ERR_HIP.
+ *   - a handle is not thread-safe; use one stepper per GPU (one process per GPU).
+ */
+#ifndef CSIM_H
+#define CSIM_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSIM_ABI_VERSION 1
+
+enum {
+    CSIM_OK = 0,
+    CSIM_ERR_ARG = 1,         /* bad argument (maps to std::out_of_range / std::runtime_error) */
+    CSIM_ERR_HIP = 2,         /* a HIP runtime call failed, or no device */
+    CSIM_ERR_RCCL = 3,        /* an RCCL call failed */
+    CSIM_ERR_STATE = 4,       /* call sequence error (e.g. multi-rank run before comm init) */
+    CSIM_ERR_UNSUPPORTED = 5
+};
+
+/* reference include/boundary.hpp:5  enum class BCType { Dirichlet, Neumann, Periodic } */
+enum { CSIM_BC_DIRICHLET = 0, CSIM_BC_NEUMANN = 1, CSIM_BC_PERIODIC = 2 };
+enum { CSIM_LEFT = 0, CSIM_RIGHT = 1, CSIM_BOTTOM = 2, CSIM_TOP = 3 };
+
+#define CSIM_NO_NEIGHBOR (-1)   /* stands for MPI_PROC_NULL */
+#define CSIM_UNIQUE_ID_BYTES 128
+
+typedef struct csim_field csim_field;     /* device mirror of reference `struct Field`       */
+typedef struct csim_stepper csim_stepper; /* the time-loop engine (reference main.cpp:93-118) */
+
+/* reference include/decomp.hpp:4-17 `struct Decomp2D` without the MPI communicator */
+typedef struct csim_decomp {
+    int size, rank;
+    int dims[2];    /* dims[0] splits x (the contiguous axis), dims[1] splits y */
+    int coords[2];
+    int nbr[4];     /* left,right = nbr_lr[0..1]; bottom,top = nbr_du[0..1]; CSIM_NO_NEIGHBOR */
+    int nx_global, ny_global;
+    int nx_local, ny_local;
+    int x_offset, y_offset;
+} csim_decomp;
+
+/* ---- library / device ------------------------------------------------------------------ */
+const char* csim_last_error(void);
+int csim_abi_version(void);
+int csim_device_count(int* count);
+int csim_set_device(int device);           /* one process per GPU: call once with LOCAL_RANK */
+int csim_device_name(char* buf, size_t n); /* gcnArchName of the current device */
+
+/* ---- host-side scalars ------------------------------------------------------------------ */
+/* reference include/stability.hpp:5-16  double safe_dt(dx,dy,vx,vy,D) */
+double csim_safe_dt(double dx, double dy, double vx, double vy, double D);
+/* reference src/decomp.cpp:5-34  Decomp2D::init(comm, nx_global, ny_global), MPI-free:
+ * MPI_Dims_create(size,2) + MPI_Cart_create(periods 0,0, reorder 0) are re-derived. */
+int csim_decomp_init(int size, int rank, int nx_global, int ny_global, csim_decomp* out);
+
+/* ---- Field (reference include/field.hpp:5-21, src/field.cpp:6-31) ------------------------ */
+int csim_field_create(int nx, int ny, int halo, double dx, double dy, csim_field** out); /* zero-filled */
+int csim_field_destroy(csim_field* f);
+int csim_field_upload(csim_field* f, const double* host_with_ghosts);
+int csim_field_download(const csim_field* f, double* host_with_ghosts);
+int csim_field_download_interior(const csim_field* f, double* host_ny_by_nx);
+int csim_field_fill(csim_field* f, double value);                 /* Field::fill            */
+int csim_field_copy(csim_field* dst, const csim_field* src);      /* std::copy, main.cpp:104 */
+int csim_field_swap(csim_field* a, csim_field* b);                /* std::swap, main.cpp:109 */
+/* wavefront-level reductions.  minmax spans the whole array, ghosts included, like
+ * reference src/main.cpp:73-77; sum/linf span the interior. */
+int csim_field_minmax(const csim_field* f, double out_min_max[2]);
+int csim_field_sum(const csim_field* f, double* out);
+int csim_field_linf_diff(const csim_field* a, const csim_field* b, double* out);
+
+/* ---- the operators at the reference's own granularity ------------------------------------ */
+/* reference src/boundary.cpp:12-54  apply_boundary(f, dec, bc, value); is_physical[s] != 0
+ * stands for "neighbour on side s is MPI_PROC_NULL". */
+int csim_apply_boundary(csim_field* f, const int bc[4], const int is_physical[4], double value);
+/* reference src/diffusion.cpp:3-26  diffusion_step(u, out, D, dt) (interior + ring copy) */
+int csim_diffusion_step(const csim_field* u, csim_field* out, double D, double dt);
+/* reference src/advection.cpp:5-34  advection_step(u, out, vx, vy, dt) (accumulates) */
+int csim_advection_step(const csim_field* u, csim_field* out, double vx, double vy, double dt);
+/* copy + diffusion_step + advection_step in ONE sweep (reference src/main.cpp:104-107):
+ * out := u everywhere, then the fused update on the interior. */
+int csim_fused_step(const csim_field* u, csim_field* out, double D, double dt, double vx, double vy);
+
+/* ---- the time loop (reference src/main.cpp:93-118 minus I/O) ------------------------------ */
+int csim_stepper_create(const csim_decomp* dec, double dx, double dy, const int bc[4],
+                        double bc_value, csim_stepper** out);
+int csim_stepper_destroy(csim_stepper* s);
+/* multi-GPU: RCCL communicator for the halo exchange (replaces MPI in reference src/halo.cpp).
+ * rank 0 calls csim_comm_unique_id, ships the 128 bytes to the other ranks by any means
+ * (MPI_Bcast, torch.distributed store, file), then every rank calls csim_stepper_comm_init. */
+int csim_comm_unique_id(void* id, size_t nbytes);
+int csim_stepper_comm_init(csim_stepper* s, const void* id, size_t nbytes);
+int csim_stepper_upload(csim_stepper* s, const double* host_with_ghosts);   /* local tile */
+int csim_stepper_download(csim_stepper* s, double* host_with_ghosts);
+int csim_stepper_download_interior(csim_stepper* s, double* host_ny_by_nx);
+/* gaussian hotspot written on the device (reference src/init.cpp:12-33) */
+int csim_stepper_init_gaussian(csim_stepper* s, double A, double sigma_frac, double xc_frac,
+                               double yc_frac);
+/* reference src/halo.cpp:6-50  exchange_halos(u, dec, comm) on the current field */
+int csim_stepper_exchange_halos(csim_stepper* s);
+/* nsteps x { exchange_halos; apply_boundary; fused sweep; swap }, enqueued without host syncs */
+int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy, int nsteps);
+int csim_stepper_sync(csim_stepper* s);
+int csim_stepper_minmax(csim_stepper* s, double out_min_max[2]);
+int csim_stepper_sum(csim_stepper* s, double* out);
+/* tuning / measurement knobs; unknown keys give CSIM_ERR_ARG.
+ *   "variant" kernel family (0 auto), "rows_per_chunk", "overlap" (0/1), "profile" (0/1) */
+int csim_stepper_set_option(csim_stepper* s, const char* key, long value);
+/* with option "profile"=1: HIP-event time of the stencil launches since the last reset */
+int csim_stepper_kernel_time(csim_stepper* s, double* total_ms, long* launches);
+int csim_stepper_reset_timers(csim_stepper* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSIM_H */

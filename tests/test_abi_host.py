@@ -1,0 +1,81 @@
+"""CPU-side checks of the product's host logic and of the C-ABI library (no GPU needed):
+the library loads, exports every symbol include/csim.h declares, and its MPI-free
+decomposition / safe_dt agree with the real MPI library / the reference header (goldens)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from __graft_entry__ import load_package
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def csim():
+    pkg = load_package()
+    pkg.build()
+    return pkg
+
+
+def test_library_exports_every_declared_symbol(csim):
+    lib = csim.lib()
+    names = csim.declared_symbols()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.csim_abi_version() == 1
+
+
+def test_decomp_matches_mpi_tables(csim):
+    z = np.load(os.path.join(GOLDEN, "decomp_table.npz"), allow_pickle=False)
+    m = json.loads(str(z["meta"]))
+    for (nx, ny) in m["grids"]:
+        for p in m["sizes"]:
+            want = z[f"g{nx}x{ny}_np{p}"]
+            for r in range(p):
+                d = csim.decomp_init(p, r, nx, ny).as_dict()
+                assert list(d.values()) == list(want[r]), (nx, ny, p, r)
+
+
+def test_decomp_rejects_bad_arguments(csim):
+    with pytest.raises(csim.CsimError):
+        csim.decomp_init(4, 4, 16, 16)
+    with pytest.raises(csim.CsimError):
+        csim.decomp_init(0, 0, 16, 16)
+    with pytest.raises(csim.CsimError):
+        csim.decomp_init(1, 0, 0, 16)
+    with pytest.raises(csim.CsimError):
+        csim.decomp_init(8, 0, 2, 2)  # more ranks than cells along x
+
+
+def test_safe_dt_matches_reference_header(csim):
+    t = np.load(os.path.join(GOLDEN, "safe_dt.npz"))["table"]
+    for dx, dy, vx, vy, D, want in t:
+        assert csim.safe_dt(dx, dy, vx, vy, D) == want
+    assert csim.safe_dt(1, 1, 0, 0, 0) == float("inf")
+
+
+def test_bc_aliases(csim):
+    # reference src/io.cpp:35-44
+    assert csim.bc_from_string("Fixed") == csim.DIRICHLET
+    assert csim.bc_from_string("noflux") == csim.NEUMANN
+    assert csim.bc_from_string("zero-flux") == csim.NEUMANN
+    assert csim.bc_from_string("period") == csim.PERIODIC
+    with pytest.raises(RuntimeError):
+        csim.bc_from_string("robin")
+
+
+def test_no_cpu_fallback_without_device(csim):
+    """On a box without a GPU the compute entry points must fail loudly, never fall back."""
+    try:
+        n = csim.device_count()
+    except csim.CsimError:
+        n = 0
+    if n > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(csim.CsimError):
+        csim.Field(8, 8)
+    with pytest.raises(csim.CsimError):
+        csim.Stepper.single(8, 8)

@@ -1,0 +1,329 @@
+"""Parity tests proper: the HIP path, called through the C ABI (include/csim.h), against
+(1) the golden vectors generated from the compiled reference and (2) the oracle on seeded
+inputs.  Everything is fp64 in the reference's association order with FMA contraction off,
+so the bar is BIT-EXACT (np.array_equal), far inside the north-star tolerance L_inf < 1e-10.
+At BASELINE.json's full sizes, parity is checked through the stencil's domain of dependence:
+after k steps a window depends only on the initial data within k cells of it, so random
+windows (incl. strip / chunk seams and physical edges) are re-computed by the oracle."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from __graft_entry__ import load_package
+from oracle import cpu_oracle as ora
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+RUN_FILES = sorted(glob.glob(os.path.join(GOLDEN, "run_*.npz")))
+VARIANT_CFGS = [dict(variant=1, prefetch=1), dict(variant=1, prefetch=2), dict(variant=1, prefetch=4),
+                dict(variant=1, prefetch=8, rows_per_chunk=7), dict(variant=1, rows_per_chunk=1),
+                dict(variant=1, xcd_swizzle=0), dict(variant=2), dict(variant=2, rows_per_chunk=5),
+                dict(variant=3)]
+
+
+@pytest.fixture(scope="module")
+def csim():
+    pkg = load_package()
+    pkg.lib()
+    assert pkg.device_count() >= 1, "no GPU visible"
+    pkg.set_device(0)
+    assert pkg.device_name().startswith("gfx950"), pkg.device_name()
+    return pkg
+
+
+def _load(path):
+    z = np.load(path, allow_pickle=False)
+    return z, json.loads(str(z["meta"]))
+
+
+def with_ghosts(interior):
+    ny, nx = interior.shape
+    f = np.zeros((ny + 2, nx + 2))
+    f[1:-1, 1:-1] = interior
+    return f
+
+
+def run_gpu(csim, u0, dx, dy, D, vx, vy, dt, bc, steps, opts=None, split=None):
+    ny, nx = u0.shape[0] - 2, u0.shape[1] - 2
+    st = csim.Stepper.single(nx, ny, dx, dy, bc)
+    for k, v in (opts or {}).items():
+        st.set_option(k, v)
+    st.upload(u0)
+    if split:  # several run() calls must compose exactly like one
+        done = 0
+        for n in split:
+            st.run(D, dt, vx, vy, n)
+            done += n
+        assert done == steps
+    else:
+        st.run(D, dt, vx, vy, steps)
+    out = st.download()
+    st.close()
+    return out
+
+
+@pytest.mark.parametrize("path", RUN_FILES, ids=[os.path.basename(p)[:-4] for p in RUN_FILES])
+def test_golden_runs_bit_exact_all_variants(csim, path):
+    z, m = _load(path)
+    dt = float(z["dt_effective"])
+    assert dt == min(m["dt"], csim.safe_dt(m["dx"], m["dy"], m["vx"], m["vy"], m["D"]))
+    u0 = with_ghosts(z["u0"])
+    want = z["local_np1_rank0"]  # full local array of the reference's 1-rank run
+    for opts in VARIANT_CFGS:
+        got = run_gpu(csim, u0, m["dx"], m["dy"], m["D"], m["vx"], m["vy"], dt,
+                      csim.bc_codes(m["bc"]), m["steps"], opts)
+        assert np.array_equal(got, want), (os.path.basename(path), opts,
+                                           float(np.abs(got - want).max()))
+
+
+def test_golden_unit_steps(csim):
+    z, cases = _load(os.path.join(GOLDEN, "unit_steps.npz"))
+    for c in cases:
+        k = c["idx"]
+        u = csim.Field(c["nx"], c["ny"], 1, c["dx"], c["dy"]).upload(z[f"c{k}_u"])
+        o = csim.Field(c["nx"], c["ny"], 1, c["dx"], c["dy"]).upload(z[f"c{k}_o"])
+        if c["op"] == "diffusion":
+            csim.diffusion_step(u, o, c["D"], c["dt"])
+        else:
+            csim.advection_step(u, o, c["vx"], c["vy"], c["dt"])
+        assert np.array_equal(o.download(), z[f"c{k}_out"]), c
+        assert np.array_equal(u.download(), z[f"c{k}_u"])
+
+
+def test_golden_boundary(csim):
+    z, cases = _load(os.path.join(GOLDEN, "boundary.npz"))
+    for c in cases:
+        k = c["idx"]
+        f = csim.Field(c["nx"], c["ny"]).upload(z[f"c{k}_in"])
+        csim.apply_boundary(f, csim.bc_codes(c["bc"]), (1, 1, 1, 1), c["value"])
+        assert np.array_equal(f.download(), z[f"c{k}_out"]), c
+
+
+def test_reference_unit_test_assertions(csim):
+    """The reference's own unit-test bodies restated against the C ABI
+    (tests/simulation/unit/test_{field,diffusion,advection,boundary}.cpp)."""
+    # test_diffusion.cpp:17-34
+    u = np.zeros((5, 5))
+    u[2, 2] = 1.0
+    fu, fv = csim.Field(3, 3).upload(u), csim.Field(3, 3)
+    csim.diffusion_step(fu, fv, 0.1, 0.1)
+    v = fv.download()
+    a = 0.01
+    assert abs(v[2, 2] - (1 - 4 * a)) < 1e-12
+    for (j, i) in [(2, 1), (2, 3), (1, 2), (3, 2)]:
+        assert abs(v[j, i] - a) < 1e-12
+    # test_advection.cpp:13-71
+    h = np.zeros((10, 10))
+    h[5, 5] = 1.0
+    fh = csim.Field(8, 8).upload(h)
+    for vx, vy, zero in [(0, 0, True), (1, 0, False), (-1, 0, False), (0, 1, False), (0, -1, False)]:
+        fo = csim.Field(8, 8)
+        fo.fill(0.0)
+        csim.advection_step(fh, fo, float(vx), float(vy), 0.1)
+        o = fo.download()
+        if zero:
+            assert (o[1:-1, 1:-1] == 0.0).all()
+        else:
+            assert o[5, 5] != 0.0
+    # test_boundary.cpp:8-69
+    f = np.full((5, 6), -1.0)
+    f[1:-1, 1:-1] = 10.0
+    ff = csim.Field(4, 3).upload(f)
+    csim.apply_boundary(ff, [0, 0, 0, 0], (1, 1, 1, 1), 5.0)
+    g = ff.download()
+    assert (g[:, 0] == 5).all() and (g[:, -1] == 5).all() and (g[0] == 5).all() and (g[-1] == 5).all()
+    f = np.full((5, 6), -1.0)
+    f[1:-1, 1:-1] = np.arange(1, 4)[:, None]
+    ff.upload(f)
+    csim.apply_boundary(ff, [1, 1, 1, 1], (1, 1, 1, 1), 0.0)
+    g = ff.download()
+    assert np.array_equal(g[:, 0], g[:, 1]) and np.array_equal(g[:, -1], g[:, -2])
+    assert np.array_equal(g[0], g[1]) and np.array_equal(g[-1], g[-2])
+    # test_field.cpp:5-26 (layout + fill), plus Field::fill / copy / swap
+    ff.fill(3.5)
+    assert (ff.download() == 3.5).all()
+    lay = (10.0 * np.arange(5)[:, None] + np.arange(6)[None, :])
+    ff.upload(lay)
+    assert np.array_equal(ff.download(), lay)
+    assert np.array_equal(ff.download_interior(), lay[1:-1, 1:-1])
+    other = csim.Field(4, 3)
+    other.copy_from(ff)
+    ff.fill(0.0)
+    other.swap(ff)
+    assert np.array_equal(ff.download(), lay) and (other.download() == 0).all()
+
+
+def test_bad_arguments_fail_loudly(csim):
+    with pytest.raises(csim.CsimError):
+        csim.Field(0, 4)
+    with pytest.raises(csim.CsimError):
+        csim.Field(4, 4, halo=2)  # reference driver is halo==1 only
+    a, b = csim.Field(4, 4), csim.Field(5, 4)
+    with pytest.raises(csim.CsimError):
+        csim.diffusion_step(a, b, 0.1, 0.1)
+    with pytest.raises(csim.CsimError):
+        csim.diffusion_step(a, a, 0.1, 0.1)
+    st = csim.Stepper.single(8, 8)
+    with pytest.raises(csim.CsimError):
+        st.set_option("no_such_option", 1)
+    st.close()
+
+
+SEEDED = [
+    # nx, ny, dx, dy, D, vx, vy, dt, bc, steps
+    (1000, 777, 1.0, 1.0, 0.05, 0.5, 0.25, 0.1, "dnpd", 11),
+    (512, 64, 1.0, 1.0, 0.2, -0.3, -0.6, 0.1, "nnnn", 9),
+    (129, 130, 0.5, 0.25, 0.01, 0.3, -0.2, 0.05, "ndpn", 13),   # exact-reciprocal path
+    (257, 33, 0.7, 1.3, 0.08, -0.6, 0.9, 0.1, "pdnd", 7),       # IEEE-division path
+    (4096, 96, 1.0, 1.0, 1.0, 0.0, 0.0, 0.1, "pppp", 6),        # config 2 physics
+    (127, 1, 1.0, 1.0, 0.1, 0.4, 0.4, 0.1, "dddd", 5),
+    (1, 300, 1.0, 1.0, 0.1, 0.4, -0.4, 0.1, "nndd", 5),
+    (2049, 515, 1.0, 1.0, 0.05, 0.5, 0.25, 0.1, "dddd", 8),     # config 3 physics, ragged strips
+]
+
+
+@pytest.mark.parametrize("case", SEEDED, ids=[f"{c[0]}x{c[1]}_{c[8]}" for c in SEEDED])
+def test_seeded_random_vs_oracle_bit_exact(csim, case):
+    nx, ny, dx, dy, D, vx, vy, dt, bc, steps = case
+    rng = np.random.default_rng(nx * 7919 + ny)
+    u0 = np.zeros((ny + 2, nx + 2))
+    u0[1:-1, 1:-1] = rng.standard_normal((ny, nx))
+    # non-zero ghosts too: periodic sides must carry them unchanged through every step (Q1)
+    u0[0, :], u0[-1, :], u0[:, 0], u0[:, -1] = 0.25, -0.5, 0.75, -1.25
+    want = u0.copy()
+    ora.run_single(want, dx, dy, D, vx, vy, dt, ora.bc_codes(bc), steps)
+    for opts in [dict(variant=1), dict(variant=2), dict(variant=1, prefetch=4, rows_per_chunk=37)]:
+        got = run_gpu(csim, u0, dx, dy, D, vx, vy, dt, csim.bc_codes(bc), steps, opts)
+        assert np.array_equal(got, want), (opts, float(np.abs(got - want).max()))
+    got = run_gpu(csim, u0, dx, dy, D, vx, vy, dt, csim.bc_codes(bc), steps, None,
+                  split=[1, 2, steps - 3])
+    assert np.array_equal(got, want)
+
+
+def test_fused_step_equals_copy_diffusion_advection(csim):
+    """csim_fused_step == std::copy + diffusion_step + advection_step (main.cpp:104-107)."""
+    rng = np.random.default_rng(3)
+    nx, ny = 333, 211
+    u = rng.standard_normal((ny + 2, nx + 2))
+    fu = csim.Field(nx, ny, 1, 0.5, 2.0).upload(u)
+    a, b = csim.Field(nx, ny, 1, 0.5, 2.0), csim.Field(nx, ny, 1, 0.5, 2.0)
+    a.copy_from(fu)
+    csim.diffusion_step(fu, a, 0.07, 0.1)
+    csim.advection_step(fu, a, -0.3, 0.2, 0.1)
+    b.fill(9.0)
+    csim.fused_step(fu, b, 0.07, 0.1, -0.3, 0.2)
+    assert np.array_equal(a.download(), b.download())
+    assert a.linf_diff(b) == 0.0
+    want = u.copy()
+    tmp = u.copy()
+    ora.diffusion_step(want, tmp, 0.5, 2.0, 0.07, 0.1)
+    ora.advection_step(want, tmp, 0.5, 2.0, -0.3, 0.2, 0.1)
+    assert np.array_equal(a.download(), tmp)
+
+
+def test_reductions(csim):
+    rng = np.random.default_rng(8)
+    nx, ny = 1234, 567
+    u = rng.standard_normal((ny + 2, nx + 2))
+    f = csim.Field(nx, ny).upload(u)
+    mn, mx = f.minmax()  # whole array, ghosts included (reference main.cpp:73-77)
+    assert mn == u.min() and mx == u.max()
+    s = f.sum()
+    ref = float(np.sum(u[1:-1, 1:-1]))
+    assert abs(s - ref) <= 1e-9 * np.abs(u[1:-1, 1:-1]).sum()
+    g = csim.Field(nx, ny).upload(u + 0.0)
+    assert f.linf_diff(g) == 0.0
+    u2 = u.copy()
+    u2[100, 200] += 0.125
+    g.upload(u2)
+    assert f.linf_diff(g) == 0.125
+
+
+def test_device_gaussian_matches_host_formula(csim):
+    """NEXT-1 row: IC on device (reference src/init.cpp:12-33); exp() may differ by an ulp."""
+    nx, ny = 640, 384
+    st = csim.Stepper.single(nx, ny, 1.0, 1.0)
+    st.init_gaussian(1.0, 0.05, 0.5, 0.5)
+    got = st.download()
+    st.close()
+    want = ora.gaussian_global(nx, ny)
+    assert (got[0] == 0).all() and (got[:, 0] == 0).all()
+    assert np.abs(got - want).max() <= 4 * np.finfo(float).eps
+
+
+# ---- BASELINE.json full sizes: domain-of-dependence windows -----------------------------------
+def _window_check(csim, nx, ny, D, vx, vy, dt, bc, steps, opts, nwin, seed):
+    st = csim.Stepper.single(nx, ny, 1.0, 1.0, csim.bc_codes(bc))
+    for k, v in (opts or {}).items():
+        st.set_option(k, v)
+    rng = np.random.default_rng(seed)
+    u0 = np.zeros((ny + 2, nx + 2))
+    u0[1:-1, 1:-1] = rng.random((ny, nx))
+    st.upload(u0)
+    st.run(D, dt, vx, vy, steps)
+    got = st.download()
+    st.close()
+    W = 96
+    anchors = [(1, 1), (nx - W + 1, 1), (1, ny - W + 1), (nx - W + 1, ny - W + 1)]
+    seams = [128, 512, 1024, nx // 2]
+    for k in range(nwin):
+        if k < len(anchors):
+            i0, j0 = anchors[k]
+        else:
+            i0 = int(rng.choice(seams)) - W // 2 + int(rng.integers(-3, 4)) if k % 2 else int(rng.integers(1, nx - W))
+            j0 = int(rng.choice([64, 128, 256])) * int(rng.integers(1, max(2, ny // 256))) - W // 2 if k % 3 == 0 else int(rng.integers(1, ny - W))
+            i0, j0 = max(1, min(i0, nx - W + 1)), max(1, min(j0, ny - W + 1))
+        # expanded window, clipped at the physical edges (where the real BC applies)
+        a0, a1 = max(1, i0 - steps), min(nx, i0 + W - 1 + steps)
+        b0, b1 = max(1, j0 - steps), min(ny, j0 + W - 1 + steps)
+        sub = u0[b0 - 1:b1 + 2, a0 - 1:a1 + 2].copy()
+        # sides cut inside the domain get a frozen (Periodic = no-op) ring: wrong values there
+        # contaminate at most `steps` cells, which lie outside the compared window
+        codes = ora.bc_codes(bc)
+        sub_bc = [codes[0] if a0 == 1 else ora.PERIODIC, codes[1] if a1 == nx else ora.PERIODIC,
+                  codes[2] if b0 == 1 else ora.PERIODIC, codes[3] if b1 == ny else ora.PERIODIC]
+        ora.run_single(sub, 1.0, 1.0, D, vx, vy, dt, sub_bc, steps)
+        wi, wj = i0 - (a0 - 1), j0 - (b0 - 1)
+        want = sub[wj:wj + W, wi:wi + W]
+        have = got[j0:j0 + W, i0:i0 + W]
+        assert np.array_equal(have, want), (k, i0, j0, float(np.abs(have - want).max()))
+    return got
+
+
+def test_full_size_config2_4096_diffusion_periodic(csim):
+    got = _window_check(csim, 4096, 4096, 1.0, 0.0, 0.0, 0.1, "pppp", 6, None, 12, 42)
+    assert np.isfinite(got).all()
+
+
+def test_full_size_config3_8192_dirichlet(csim):
+    _window_check(csim, 8192, 8192, 0.05, 0.5, 0.25, 0.1, "dddd", 5, None, 12, 43)
+
+
+def test_full_size_16384_windows(csim):
+    _window_check(csim, 16384, 16384, 0.05, 0.5, 0.25, 0.1, "dnnd", 4, None, 10, 44)
+
+
+def test_physics_sanity_like_reference_integration_tests(csim):
+    """reference tests/simulation/integration/integration_{diffusion,advection}.cpp: the peak of
+    a diffusing hotspot decreases and stays >= 0; an advected hotspot's centre of mass moves by
+    ~v*t with mass kept within 5 %."""
+    nx = ny = 64
+    u0 = ora.gaussian_global(nx, ny)
+    st = csim.Stepper.single(nx, ny)
+    st.upload(u0)
+    st.run(1.0, 0.1, 0.0, 0.0, 9)
+    d = st.download_interior()
+    assert d.max() < u0.max() and (d >= 0).all()
+    st.upload(u0)
+    st.run(0.0, 1.0, 1.0, 0.0, 5)  # vx=1, dt=1 (CFL limit), 5 steps
+    a = st.download_interior()
+    st.close()
+    x = np.arange(nx)[None, :]
+    com0 = (u0[1:-1, 1:-1] * x).sum() / u0[1:-1, 1:-1].sum()
+    com1 = (a * x).sum() / a.sum()
+    assert abs((com1 - com0) - 5.0) <= 1.0
+    assert abs(a.sum() - u0.sum()) <= 0.05 * u0.sum()
