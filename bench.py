@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--rows-per-chunk", type=int, default=0)
     ap.add_argument("--prefetch", type=int, default=0)
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--no-fuse", action="store_true", help="one time step per HBM pass only")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -114,7 +115,8 @@ def main():
         dist.broadcast_object_list(box, src=0)
         st.comm_init(box[0])
     for key, val in (("variant", args.variant), ("rows_per_chunk", args.rows_per_chunk),
-                     ("prefetch", args.prefetch), ("overlap", 0 if args.no_overlap else 1)):
+                     ("prefetch", args.prefetch), ("overlap", 0 if args.no_overlap else 1),
+                     ("fuse", 0 if args.no_fuse else 1)):
         st.set_option(key, val)
     st.init_gaussian(1.0, 0.05, 0.5, 0.5)
     dt = min(PHYS["dt"], csim.safe_dt(1.0, 1.0, PHYS["vx"], PHYS["vy"], PHYS["D"]))
@@ -138,22 +140,23 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kern_ms, launches = st.kernel_time()
+    kern_ms, launches, steps_cov = st.kernel_time()
     mn, mx = st.minmax()
     st.close()
     if world > 1:
-        km = torch.tensor([kern_ms / max(launches, 1)], dtype=torch.float64)
+        km = torch.tensor([kern_ms], dtype=torch.float64)
         dist.all_reduce(km, op=dist.ReduceOp.MAX)
-        kern_avg_ms = float(km.item())
+        kern_ms = float(km.item())
         dist.destroy_process_group()
-    else:
-        kern_avg_ms = kern_ms / max(launches, 1)
+    kern_avg_ms = kern_ms / max(launches, 1)
+    steps_per_launch = steps_cov / max(launches, 1)
 
     if rank == 0:
         cells = float(args.nx) * float(args.ny)
         value = cells * args.steps / elapsed / 1e6
         local_cells = float(dec.nx_local) * float(dec.ny_local)
-        ach = local_cells * BYTES_PER_CELL / (kern_avg_ms * 1e-3) / 1e9
+        # algorithmic bytes of ONE launch = 16 B x local cells x time steps that launch advances
+        ach = local_cells * BYTES_PER_CELL * steps_per_launch / (kern_avg_ms * 1e-3) / 1e9
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if world == 1 and os.path.exists(tfile):
@@ -191,10 +194,12 @@ def main():
                 "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "kernel": "k_sweep (fused copy+diffusion+advection)",
+                "kernel": "fused sweep (copy+diffusion+advection; k_sweep2_dpp advances 2 steps "
+                          "per HBM pass, k_sweep_dpp 1)",
                 "kernel_avg_ms": kern_avg_ms,
                 "launches_timed": launches,
-                "algorithmic_bytes_per_launch": local_cells * BYTES_PER_CELL,
+                "time_steps_per_launch": steps_per_launch,
+                "algorithmic_bytes_per_launch": local_cells * BYTES_PER_CELL * steps_per_launch,
             },
         }
         if cpu is not None:

@@ -126,7 +126,7 @@ def lib() -> C.CDLL:
         "csim_stepper_minmax": (i, [vp, dp]),
         "csim_stepper_sum": (i, [vp, dp]),
         "csim_stepper_set_option": (i, [vp, C.c_char_p, C.c_long]),
-        "csim_stepper_kernel_time": (i, [vp, dp, C.POINTER(C.c_long)]),
+        "csim_stepper_kernel_time": (i, [vp, dp, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
         "csim_stepper_reset_timers": (i, [vp]),
     }
     for name, (res, args) in sig.items():
@@ -348,9 +348,9 @@ class Stepper:
         _ck(lib().csim_stepper_set_option(self._h, key.encode(), int(value)))
 
     def kernel_time(self):
-        ms, n = C.c_double(), C.c_long()
-        _ck(lib().csim_stepper_kernel_time(self._h, C.byref(ms), C.byref(n)))
-        return ms.value, n.value
+        ms, n, st = C.c_double(), C.c_long(), C.c_long()
+        _ck(lib().csim_stepper_kernel_time(self._h, C.byref(ms), C.byref(n), C.byref(st)))
+        return ms.value, n.value, st.value
 
     def reset_timers(self):
         _ck(lib().csim_stepper_reset_timers(self._h))

@@ -113,7 +113,8 @@ struct csim_stepper {
     int phys[4]{1, 1, 1, 1};
     double bc_value = 0.0;
     int nx = 0, ny = 0, pitch = 0;
-    double* cur = nullptr;
+    double* buf[2]{nullptr, nullptr};  // allocations: (ny + 4) rows, see internal.hpp
+    double* cur = nullptr;             // views (row j = 0) into buf[], ping-pong
     double* nxt = nullptr;
     double* scratch = nullptr;
     double* send[4]{nullptr, nullptr, nullptr, nullptr};
@@ -125,12 +126,17 @@ struct csim_stepper {
     bool halo_fresh = false;  // recv[] holds the neighbours' edge lines of `cur`
     SweepCfg cfg;
     int overlap = 1;
+    int fuse = 1;  // two time steps per HBM pass where the kernel supports it
     int profile = 0;
     std::vector<hipEvent_t> ev_pool;  // start/stop pairs around sweep launches
+    std::vector<int> ev_steps;        // time steps covered by each timed launch
     size_t ev_used = 0;
     double prof_ms = 0.0;
     long prof_launches = 0;
-    size_t bytes() const { return sizeof(double) * static_cast<size_t>(ny + 2) * pitch; }
+    long prof_steps = 0;
+    size_t bytes() const { return sizeof(double) * static_cast<size_t>(ny + 4) * pitch; }
+    // whole-allocation pointer of a view
+    double* base(double* view) const { return view - pitch; }
 };
 
 extern "C" {
@@ -215,12 +221,13 @@ int csim_field_create(int nx, int ny, int halo, double dx, double dy, csim_field
     f->dx = dx;
     f->dy = dy;
     f->pitch = pitch_for(nx);
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&f->d), f->bytes());
-    if (e == hipSuccess) e = hipMemset(f->d, 0, f->bytes());
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&f->alloc), f->bytes());
+    if (e == hipSuccess) e = hipMemset(f->alloc, 0, f->bytes());
+    if (e == hipSuccess) f->d = f->alloc + f->pitch;
     if (e == hipSuccess)
         e = hipMalloc(reinterpret_cast<void**>(&f->scratch), sizeof(double) * 2 * REDUCE_BLOCKS);
     if (e != hipSuccess) {
-        if (f->d) (void)hipFree(f->d);
+        if (f->alloc) (void)hipFree(f->alloc);
         delete f;
         return fail(CSIM_ERR_HIP, std::string("csim_field_create: ") + hipGetErrorString(e));
     }
@@ -230,7 +237,7 @@ int csim_field_create(int nx, int ny, int halo, double dx, double dy, csim_field
 
 int csim_field_destroy(csim_field* f) {
     if (!f) return CSIM_OK;
-    if (f->d) (void)hipFree(f->d);
+    if (f->alloc) (void)hipFree(f->alloc);
     if (f->scratch) (void)hipFree(f->scratch);
     delete f;
     return CSIM_OK;
@@ -262,12 +269,13 @@ static bool same_shape(const csim_field* a, const csim_field* b) {
 
 int csim_field_copy(csim_field* dst, const csim_field* src) {
     CSIM_REQUIRE(same_shape(dst, src), "fields differ in shape");
-    CSIM_HIP(hipMemcpy(dst->d, src->d, src->bytes(), hipMemcpyDeviceToDevice));
+    CSIM_HIP(hipMemcpy(dst->alloc, src->alloc, src->bytes(), hipMemcpyDeviceToDevice));
     return CSIM_OK;
 }
 
 int csim_field_swap(csim_field* a, csim_field* b) {
     CSIM_REQUIRE(same_shape(a, b), "fields differ in shape");
+    std::swap(a->alloc, b->alloc);
     std::swap(a->d, b->d);
     return CSIM_OK;
 }
@@ -373,9 +381,9 @@ int csim_stepper_create(const csim_decomp* dec, double dx, double dy, const int 
         if (e == hipSuccess) e = r;
         return e == hipSuccess;
     };
-    ok(hipMalloc(reinterpret_cast<void**>(&s->cur), s->bytes())) &&
-        ok(hipMalloc(reinterpret_cast<void**>(&s->nxt), s->bytes())) &&
-        ok(hipMemset(s->cur, 0, s->bytes())) && ok(hipMemset(s->nxt, 0, s->bytes())) &&
+    ok(hipMalloc(reinterpret_cast<void**>(&s->buf[0]), s->bytes())) &&
+        ok(hipMalloc(reinterpret_cast<void**>(&s->buf[1]), s->bytes())) &&
+        ok(hipMemset(s->buf[0], 0, s->bytes())) && ok(hipMemset(s->buf[1], 0, s->bytes())) &&
         ok(hipMalloc(reinterpret_cast<void**>(&s->scratch), sizeof(double) * 2 * REDUCE_BLOCKS)) &&
         ok(hipStreamCreateWithFlags(&s->s_comp, hipStreamNonBlocking)) &&
         ok(hipStreamCreateWithFlags(&s->s_comm, hipStreamNonBlocking)) &&
@@ -389,6 +397,10 @@ int csim_stepper_create(const csim_decomp* dec, double dx, double dy, const int 
             ok(hipMemset(s->send[k], 0, n)) && ok(hipMemset(s->recv[k], 0, n));
     }
     if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) {
+        s->cur = s->buf[0] + s->pitch;
+        s->nxt = s->buf[1] + s->pitch;
+    }
     if (e != hipSuccess) {
         csim_stepper_destroy(s);
         return fail(CSIM_ERR_HIP, std::string("csim_stepper_create: ") + hipGetErrorString(e));
@@ -411,8 +423,8 @@ int csim_stepper_destroy(csim_stepper* s) {
     if (s->ev_recv) (void)hipEventDestroy(s->ev_recv);
     if (s->s_comp) (void)hipStreamDestroy(s->s_comp);
     if (s->s_comm) (void)hipStreamDestroy(s->s_comm);
-    if (s->cur) (void)hipFree(s->cur);
-    if (s->nxt) (void)hipFree(s->nxt);
+    if (s->buf[0]) (void)hipFree(s->buf[0]);
+    if (s->buf[1]) (void)hipFree(s->buf[1]);
     if (s->scratch) (void)hipFree(s->scratch);
     delete s;
     return CSIM_OK;
@@ -443,7 +455,12 @@ int csim_stepper_upload(csim_stepper* s, const double* host) {
     int rc = upload_2d(s->cur, s->nx, s->ny, s->pitch, host);
     if (rc) return rc;
     // both ping-pong buffers start with the same ghost ring (reference main.cpp:104 copies u->tmp)
-    CSIM_HIP(hipMemcpy(s->nxt, s->cur, s->bytes(), hipMemcpyDeviceToDevice));
+    // (a device-to-device hipMemcpy may return before it has run, and the stepper's streams do
+    // not synchronise with the null stream: order the copy on the compute stream and wait)
+    CSIM_HIP(hipDeviceSynchronize());
+    CSIM_HIP(hipMemcpyAsync(s->base(s->nxt), s->base(s->cur), s->bytes(), hipMemcpyDeviceToDevice,
+                            s->s_comp));
+    CSIM_HIP(hipStreamSynchronize(s->s_comp));
     s->halo_fresh = false;
     return CSIM_OK;
 }
@@ -464,11 +481,12 @@ int csim_stepper_init_gaussian(csim_stepper* s, double A, double sigma_frac, dou
                                double yc_frac) {
     CSIM_REQUIRE(s, "null stepper");
     CSIM_HIP(hipStreamSynchronize(s->s_comm));
-    CSIM_HIP(hipMemsetAsync(s->cur, 0, s->bytes(), s->s_comp));
+    CSIM_HIP(hipMemsetAsync(s->base(s->cur), 0, s->bytes(), s->s_comp));
     CSIM_HIP(launch_gaussian(s->cur, s->nx, s->ny, s->pitch, s->dec.x_offset, s->dec.y_offset,
                              s->dec.nx_global, s->dec.ny_global, s->dx, s->dy, A, sigma_frac,
                              xc_frac, yc_frac, s->s_comp));
-    CSIM_HIP(hipMemcpyAsync(s->nxt, s->cur, s->bytes(), hipMemcpyDeviceToDevice, s->s_comp));
+    CSIM_HIP(hipMemcpyAsync(s->base(s->nxt), s->base(s->cur), s->bytes(), hipMemcpyDeviceToDevice,
+                            s->s_comp));
     CSIM_HIP(hipStreamSynchronize(s->s_comp));
     s->halo_fresh = false;
     return CSIM_OK;
@@ -538,6 +556,7 @@ static int prof_fold(csim_stepper* s) {
         CSIM_HIP(hipEventElapsedTime(&ms, s->ev_pool[k], s->ev_pool[k + 1]));
         s->prof_ms += ms;
         s->prof_launches += 1;
+        s->prof_steps += s->ev_steps[k / 2];
     }
     s->ev_used = 0;
     return CSIM_OK;
@@ -550,8 +569,16 @@ int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy,
         return fail(CSIM_ERR_STATE, "multi-rank stepper needs csim_stepper_comm_init before run");
     const Phys p = make_phys(s->dx, s->dy, D, dt, vx, vy);
     const GhostArgs g = ghost_args(s);
+    // Two steps per HBM pass where possible.  The LAST step of a call is always a single-step
+    // pass so that the ghost ring left in the field is exactly the reference's (the ring of
+    // the state before the last step, src/main.cpp:104 + src/diffusion.cpp:18-25).
+    const bool can2 = s->fuse && !s->multi && sweep2_supported(s->nx, s->cfg);
+    int kind2[4];
+    for (int k = 0; k < 4; ++k) kind2[k] = s->phys[k] ? s->bc[k] : 3;
     constexpr size_t POOL = 2048;
-    for (int n = 0; n < nsteps; ++n) {
+    int remaining = nsteps;
+    while (remaining > 0) {
+        const int t = (can2 && remaining >= 3) ? 2 : 1;
         if (s->multi) {
             if (!s->halo_fresh) {
                 int rc = refresh_halos(s);  // on s_comp: ordered before the ghost fill
@@ -581,15 +608,22 @@ int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy,
                 CSIM_HIP(hipEventCreate(&ev));
                 s->ev_pool.push_back(ev);
             }
+            if (s->ev_steps.size() < s->ev_pool.size() / 2) s->ev_steps.resize(s->ev_pool.size() / 2);
+            s->ev_steps[s->ev_used / 2] = t;
             CSIM_HIP(hipEventRecord(s->ev_pool[s->ev_used], s->s_comp));
         }
-        CSIM_HIP(launch_sweep(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, s->cfg, s->s_comp));
+        if (t == 2)
+            CSIM_HIP(launch_sweep2(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, s->cfg, kind2,
+                                   s->bc_value, s->s_comp));
+        else
+            CSIM_HIP(launch_sweep(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, s->cfg, s->s_comp));
         if (s->profile) {
             CSIM_HIP(hipEventRecord(s->ev_pool[s->ev_used + 1], s->s_comp));
             s->ev_used += 2;
         }
         std::swap(s->cur, s->nxt);
         if (s->multi && !s->overlap) s->halo_fresh = false;  // serial mode: re-exchange next step
+        remaining -= t;
     }
     return CSIM_OK;
 }
@@ -632,6 +666,8 @@ int csim_stepper_set_option(csim_stepper* s, const char* key, long value) {
         s->cfg.xcd_swizzle = value != 0;
     } else if (k == "overlap") {
         s->overlap = value != 0;
+    } else if (k == "fuse") {
+        s->fuse = value != 0;
     } else if (k == "profile") {
         s->profile = value != 0;
     } else {
@@ -640,12 +676,13 @@ int csim_stepper_set_option(csim_stepper* s, const char* key, long value) {
     return CSIM_OK;
 }
 
-int csim_stepper_kernel_time(csim_stepper* s, double* total_ms, long* launches) {
-    CSIM_REQUIRE(s && total_ms && launches, "null argument");
+int csim_stepper_kernel_time(csim_stepper* s, double* total_ms, long* launches, long* steps) {
+    CSIM_REQUIRE(s && total_ms && launches && steps, "null argument");
     int rc = prof_fold(s);
     if (rc) return rc;
     *total_ms = s->prof_ms;
     *launches = s->prof_launches;
+    *steps = s->prof_steps;
     return CSIM_OK;
 }
 
@@ -655,6 +692,7 @@ int csim_stepper_reset_timers(csim_stepper* s) {
     if (rc) return rc;
     s->prof_ms = 0.0;
     s->prof_launches = 0;
+    s->prof_steps = 0;
     return CSIM_OK;
 }
 

@@ -4,9 +4,12 @@
 // so that the FIRST INTERIOR column (i = 1) of every row starts on a 128-byte boundary and a
 // 64-lane wavefront reading 2 doubles per lane covers exactly 8 full 128-byte lines:
 //
-//     element (i, j), 0 <= i <= nx+1, 0 <= j <= ny+1   ->   base[j * pitch + (LPAD - 1) + i]
+//     element (i, j), 0 <= i <= nx+1, 0 <= j <= ny+1   ->   view[j * pitch + (LPAD - 1) + i]
 //
 //     | 15 unused | ghost i=0 | interior i=1..nx (128-B aligned) | ghost i=nx+1 | pad ... |
+//
+// `view` points one row into the allocation: rows -1 and ny+2 and columns -1 and nx+2 exist as
+// a second (device-only) ghost layer, which the two-steps-per-pass sweep reads.
 //
 // pitch = LPAD + round_up(nx + 1, 128) + 16 doubles; for nx = 16384 that is 16544 doubles =
 // 132352 B, an odd multiple of 256 B, so vertically adjacent rows do not alias onto one HBM
@@ -65,6 +68,10 @@ struct SweepCfg {
 // All pointers are device pointers in the padded layout above.
 hipError_t launch_sweep(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
                         const SweepCfg& cfg, hipStream_t st);
+// two fused time steps per pass; kind[s] = CSIM_BC_* on physical sides, 3 on neighbour sides
+bool sweep2_supported(int nx, const SweepCfg& cfg);
+hipError_t launch_sweep2(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
+                         const SweepCfg& cfg, const int kind[4], double value, hipStream_t st);
 hipError_t launch_diffusion_only(const double* in, double* out, int nx, int ny, int pitch,
                                  const Phys& p, hipStream_t st);
 hipError_t launch_advection_only(const double* in, double* out, int nx, int ny, int pitch,
@@ -106,7 +113,8 @@ struct csim_field {
     int nx = 0, ny = 0, halo = 1;
     double dx = 1.0, dy = 1.0;
     int pitch = 0;
-    double* d = nullptr;        // (ny + 2) * pitch doubles
+    double* alloc = nullptr;    // (ny + 4) * pitch doubles
+    double* d = nullptr;        // view: alloc + pitch, i.e. row j = 0 of the reference layout
     double* scratch = nullptr;  // reduction partials
-    size_t bytes() const { return sizeof(double) * static_cast<size_t>(ny + 2) * pitch; }
+    size_t bytes() const { return sizeof(double) * static_cast<size_t>(ny + 4) * pitch; }
 };

@@ -173,6 +173,152 @@ __global__ __launch_bounds__(256) void k_sweep_dpp(const double* __restrict__ in
 }
 
 // -------------------------------------------------------------------------------------------
+// Two time steps per HBM pass (temporal blocking).  Same tiling as k_sweep_dpp, but while a
+// wavefront marches up its strip it keeps TWO time levels in registers: level n rows (loaded),
+// level n+1 rows (never stored) and emits level n+2.  HBM traffic per cell stays one 8-byte
+// read + one 8-byte write per PASS, i.e. half of it per step, which is what lifts the sweep
+// above the one-step copy ceiling.  The per-cell arithmetic is unchanged, so results stay
+// bit-identical to two single steps.
+//   - level n+1 is needed one column beyond the strip on each side: lanes 0 / 63 carry that
+//     extra column (they load the two outer columns of every row as one 16-byte edge load).
+//   - level n+1 is needed one row beyond the chunk: rows jb-1 .. je+1, from level-n rows
+//     jb-2 .. je+2 (the device layout keeps two ghost rows/columns for this).
+//   - where the strip/chunk touches a PHYSICAL edge, the level n+1 ghost value is not a stencil
+//     result but the boundary rule applied to level n+1 (reference src/boundary.cpp:23-53 run
+//     at the start of step n+1): Dirichlet -> value, Neumann -> adjacent interior at n+1,
+//     Periodic (no-op) -> the stored ghost, unchanged.  kind 3 = side has a
+//     neighbour rank: plain stencil on the stored depth-2 halo.
+// Requires nx % 128 == 0 (every BASELINE grid and tile); other widths use the one-step kernel.
+// -------------------------------------------------------------------------------------------
+struct Bc2 {
+    int kind[4];  // per side: CSIM_BC_* or 3 (= not a physical edge)
+    double value;
+};
+
+template <int DIV, int PF>
+__global__ __launch_bounds__(256) void k_sweep2_dpp(const double* __restrict__ in,
+                                                    double* __restrict__ out, int nx, int ny,
+                                                    int pitch, int ry, int nwgx, int swz, Phys p,
+                                                    Bc2 bc) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int lin = xcd_remap(blockIdx.x, gridDim.x, swz);
+    const int wgx = lin % nwgx, chunk = lin / nwgx;
+    const int c0 = (wgx * 4 + wave) * WAVE_COLS;
+    if (c0 >= nx) return;  // wave-uniform
+    const int jb = chunk * ry + 1;
+    const int je = min(jb + ry - 1, ny);
+    const ptrdiff_t xoff = LPAD + c0 + 2 * lane;
+    const bool lane0 = lane == 0;
+    const bool edge_lane = lane0 || (lane == 63);
+    const ptrdiff_t eoff = LPAD + c0 + (lane0 ? -2 : WAVE_COLS);
+    // boundary kind seen by this wave on each side (3 = keep the stencil)
+    const int kl = c0 == 0 ? bc.kind[CSIM_LEFT] : 3;
+    const int kr = c0 + WAVE_COLS == nx ? bc.kind[CSIM_RIGHT] : 3;
+    const int kb = jb == 1 ? bc.kind[CSIM_BOTTOM] : 3;
+    const int kt = je == ny ? bc.kind[CSIM_TOP] : 3;
+    const int kx = lane0 ? kl : kr;  // rule for this lane's extra column
+
+    auto ld2 = [&](int j) {
+        return *reinterpret_cast<const double2*>(in + static_cast<ptrdiff_t>(j) * pitch + xoff);
+    };
+    auto lde = [&](int j) {
+        double2 e = make_double2(0.0, 0.0);
+        if (edge_lane) e = *reinterpret_cast<const double2*>(in + static_cast<ptrdiff_t>(j) * pitch + eoff);
+        return e;
+    };
+
+    double2 aS = ld2(jb - 2), aC = ld2(jb - 1);
+    double2 eS = lde(jb - 2), eC = lde(jb - 1);
+    double2 q[PF], eq[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        q[u] = make_double2(0.0, 0.0);
+        eq[u] = make_double2(0.0, 0.0);
+        const int r = jb + u;
+        if (r <= je + 2) {
+            q[u] = ld2(r);
+            eq[u] = lde(r);
+        }
+    }
+    double2 bSS = make_double2(0.0, 0.0), bS = make_double2(0.0, 0.0);
+    double xS = 0.0;
+    const int rlast = je + 1;
+    for (int r0 = jb - 1; r0 <= rlast; r0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int r = r0 + u;  // row of level n+1 produced in this sub-iteration
+            if (r <= rlast) {      // wave-uniform
+                const double2 aN = q[u];
+                const double2 eN = eq[u];
+                const int rn = r + 1 + PF;
+                if (rn <= je + 2) {
+                    q[u] = ld2(rn);
+                    eq[u] = lde(rn);
+                }
+                // ---- level n+1, row r --------------------------------------------------
+                double2 b;
+                double x;
+                const bool gb = (r == 0) && (kb != 3);
+                const bool gt = (r == ny + 1) && (kt != 3);
+                if (gb || gt) {  // ghost ROW of level n+1: boundary rule, not a stencil
+                    const int k = gb ? kb : kt;
+                    if (k == CSIM_BC_DIRICHLET) {
+                        b = make_double2(bc.value, bc.value);
+                        x = bc.value;
+                    } else if (k == CSIM_BC_PERIODIC) {
+                        b = aC;
+                        x = lane0 ? eC.y : eC.x;
+                    } else if (gt) {  // Neumann top: copy of row ny at level n+1
+                        b = bS;
+                        x = xS;
+                    } else {  // Neumann bottom: patched below once row 1 exists
+                        b = make_double2(0.0, 0.0);
+                        x = 0.0;
+                    }
+                } else {
+                    const double Wx = from_prev_lane(aC.y, eC.y);
+                    const double Ey = from_next_lane(aC.x, eC.x);
+                    b.x = cell<DIV>(aC.x, Wx, aC.y, aS.x, aN.x, p);
+                    b.y = cell<DIV>(aC.y, aC.x, Ey, aS.y, aN.y, p);
+                    // the extra column: lane 0 owns column c0-1, lane 63 column c0+128
+                    const double xc = lane0 ? eC.y : eC.x;
+                    const double xw = lane0 ? eC.x : aC.y;
+                    const double xe = lane0 ? aC.x : eC.y;
+                    const double xs = lane0 ? eS.y : eS.x;
+                    const double xn = lane0 ? eN.y : eN.x;
+                    const double xst = cell<DIV>(xc, xw, xe, xs, xn, p);
+                    x = kx == 3 ? xst
+                        : kx == CSIM_BC_DIRICHLET ? bc.value
+                        : kx == CSIM_BC_NEUMANN ? (lane0 ? b.x : b.y)
+                                                : xc;
+                }
+                if (r == 1 && kb == CSIM_BC_NEUMANN) {  // level n+1 bottom ghost row := row 1
+                    bS = b;
+                    xS = x;
+                }
+                // ---- level n+2, row r-1 ------------------------------------------------
+                if (r - 1 >= jb) {
+                    const double Wx = from_prev_lane(bS.y, xS);
+                    const double Ey = from_next_lane(bS.x, xS);
+                    const double ox = cell<DIV>(bS.x, Wx, bS.y, bSS.x, b.x, p);
+                    const double oy = cell<DIV>(bS.y, bS.x, Ey, bSS.y, b.y, p);
+                    *reinterpret_cast<double2*>(out + static_cast<ptrdiff_t>(r - 1) * pitch + xoff) =
+                        make_double2(ox, oy);
+                }
+                bSS = bS;
+                bS = b;
+                xS = x;
+                aS = aC;
+                aC = aN;
+                eS = eC;
+                eC = eN;
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------
 // VAR_LDS — LDS-staged marching sweep.  A 256-thread workgroup owns a 512-column strip; every
 // row is loaded once (16 B per lane), staged in a double-buffered LDS row (ds_write_b128) with
 // its two halo columns, and the W/E neighbours are read back from LDS (ds_read_b64); N/S stay
@@ -555,6 +701,43 @@ static hipError_t sweep_div(const double* in, double* out, int nx, int ny, int p
                                ry, nwgx, cfg.xcd_swizzle, p);
     }
     return hipGetLastError();
+}
+
+template <int DIV>
+static hipError_t sweep2_div(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
+                             const SweepCfg& cfg, const Bc2& bc, hipStream_t st) {
+    int ry = cfg.rows_per_chunk > 0 ? cfg.rows_per_chunk : 64;
+    if (ry > ny) ry = ny;
+    const int nchunks = cdiv(ny, ry);
+    const int nwgx = cdiv(cdiv(nx, WAVE_COLS), 4);
+    const dim3 grid(nwgx * nchunks);
+    const int pf = cfg.prefetch > 0 ? cfg.prefetch : 2;
+    if (pf <= 1)
+        hipLaunchKernelGGL((k_sweep2_dpp<DIV, 1>), grid, dim3(256), 0, st, in, out, nx, ny, pitch, ry,
+                           nwgx, cfg.xcd_swizzle, p, bc);
+    else if (pf == 2)
+        hipLaunchKernelGGL((k_sweep2_dpp<DIV, 2>), grid, dim3(256), 0, st, in, out, nx, ny, pitch, ry,
+                           nwgx, cfg.xcd_swizzle, p, bc);
+    else
+        hipLaunchKernelGGL((k_sweep2_dpp<DIV, 4>), grid, dim3(256), 0, st, in, out, nx, ny, pitch, ry,
+                           nwgx, cfg.xcd_swizzle, p, bc);
+    return hipGetLastError();
+}
+
+bool sweep2_supported(int nx, const SweepCfg& cfg) {
+    return nx % WAVE_COLS == 0 && (cfg.variant == VAR_AUTO || cfg.variant == VAR_DPP);
+}
+
+hipError_t launch_sweep2(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
+                         const SweepCfg& cfg, const int kind[4], double value, hipStream_t st) {
+    Bc2 bc;
+    for (int s = 0; s < 4; ++s) bc.kind[s] = kind[s];
+    bc.value = value;
+    switch (p.div_mode) {
+        case 0: return sweep2_div<0>(in, out, nx, ny, pitch, p, cfg, bc, st);
+        case 1: return sweep2_div<1>(in, out, nx, ny, pitch, p, cfg, bc, st);
+        default: return sweep2_div<2>(in, out, nx, ny, pitch, p, cfg, bc, st);
+    }
 }
 
 hipError_t launch_sweep(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,

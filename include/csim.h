@@ -126,10 +126,13 @@ int csim_stepper_sync(csim_stepper* s);
 int csim_stepper_minmax(csim_stepper* s, double out_min_max[2]);
 int csim_stepper_sum(csim_stepper* s, double* out);
 /* tuning / measurement knobs; unknown keys give CSIM_ERR_ARG.
- *   "variant" kernel family (0 auto), "rows_per_chunk", "overlap" (0/1), "profile" (0/1) */
+ *   "variant" kernel family (0 auto, 1 dpp, 2 lds, 3 naive), "rows_per_chunk", "prefetch",
+ *   "xcd_swizzle" (0/1), "fuse" (0/1: two time steps per HBM pass), "overlap" (0/1: halo
+ *   exchange on the second stream), "profile" (0/1) */
 int csim_stepper_set_option(csim_stepper* s, const char* key, long value);
-/* with option "profile"=1: HIP-event time of the stencil launches since the last reset */
-int csim_stepper_kernel_time(csim_stepper* s, double* total_ms, long* launches);
+/* with option "profile"=1: HIP-event time of the sweep launches since the last reset, their
+ * count, and the number of time steps they covered (a fused launch covers two) */
+int csim_stepper_kernel_time(csim_stepper* s, double* total_ms, long* launches, long* steps);
 int csim_stepper_reset_timers(csim_stepper* s);
 
 #ifdef __cplusplus

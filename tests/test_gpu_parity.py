@@ -22,7 +22,7 @@ RUN_FILES = sorted(glob.glob(os.path.join(GOLDEN, "run_*.npz")))
 VARIANT_CFGS = [dict(variant=1, prefetch=1), dict(variant=1, prefetch=2), dict(variant=1, prefetch=4),
                 dict(variant=1, prefetch=8, rows_per_chunk=7), dict(variant=1, rows_per_chunk=1),
                 dict(variant=1, xcd_swizzle=0), dict(variant=2), dict(variant=2, rows_per_chunk=5),
-                dict(variant=3)]
+                dict(variant=3), dict(fuse=0)]
 
 
 @pytest.fixture(scope="module")
@@ -183,6 +183,15 @@ SEEDED = [
     (127, 1, 1.0, 1.0, 0.1, 0.4, 0.4, 0.1, "dddd", 5),
     (1, 300, 1.0, 1.0, 0.1, 0.4, -0.4, 0.1, "nndd", 5),
     (2049, 515, 1.0, 1.0, 0.05, 0.5, 0.25, 0.1, "dddd", 8),     # config 3 physics, ragged strips
+    # widths that are multiples of 128 take the two-steps-per-pass kernel by default
+    (128, 5, 1.0, 1.0, 0.1, 0.3, -0.2, 0.1, "dnpd", 9),
+    (256, 1, 1.0, 1.0, 0.1, -0.3, 0.2, 0.1, "nnnn", 8),
+    (128, 2, 1.0, 1.0, 0.1, 0.3, 0.2, 0.1, "pppp", 7),
+    (384, 130, 1.0, 1.0, 0.15, -0.4, -0.1, 0.1, "nnnn", 12),
+    (1024, 200, 1.0, 1.0, 0.05, 0.5, 0.25, 0.1, "pnnp", 10),
+    (640, 67, 1.0, 1.0, 0.05, 0.5, -0.25, 0.1, "ndnd", 11),
+    (256, 40, 0.5, 0.25, 0.01, 0.3, -0.2, 0.05, "dnnd", 9),     # exact-reciprocal path, fused
+    (128, 30, 0.7, 1.3, 0.08, -0.6, 0.9, 0.1, "npdn", 7),       # IEEE-division path, fused
 ]
 
 
@@ -196,7 +205,9 @@ def test_seeded_random_vs_oracle_bit_exact(csim, case):
     u0[0, :], u0[-1, :], u0[:, 0], u0[:, -1] = 0.25, -0.5, 0.75, -1.25
     want = u0.copy()
     ora.run_single(want, dx, dy, D, vx, vy, dt, ora.bc_codes(bc), steps)
-    for opts in [dict(variant=1), dict(variant=2), dict(variant=1, prefetch=4, rows_per_chunk=37)]:
+    for opts in [dict(variant=1), dict(variant=2), dict(variant=1, prefetch=4, rows_per_chunk=37),
+                 dict(fuse=0), dict(fuse=1, rows_per_chunk=1), dict(fuse=1, rows_per_chunk=3, prefetch=1),
+                 dict(fuse=1, rows_per_chunk=64, prefetch=4), dict(fuse=1, xcd_swizzle=0)]:
         got = run_gpu(csim, u0, dx, dy, D, vx, vy, dt, csim.bc_codes(bc), steps, opts)
         assert np.array_equal(got, want), (opts, float(np.abs(got - want).max()))
     got = run_gpu(csim, u0, dx, dy, D, vx, vy, dt, csim.bc_codes(bc), steps, None,

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--ry", type=int, nargs="+", default=[32, 64, 128, 256])
     ap.add_argument("--pf", type=int, nargs="+", default=[1, 2, 4, 8])
     ap.add_argument("--swz", type=int, nargs="+", default=[1])
+    ap.add_argument("--fuse", type=int, nargs="+", default=[0, 1])
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     csim = load_package()
@@ -34,24 +35,24 @@ def main():
         cfgs = []
         for v in args.variants:
             if v == 1:
-                cfgs += [dict(variant=1, rows_per_chunk=r, prefetch=p, xcd_swizzle=s)
-                         for r, p, s in itertools.product(args.ry, args.pf, args.swz)]
+                cfgs += [dict(variant=1, rows_per_chunk=r, prefetch=p, xcd_swizzle=s, fuse=f)
+                         for r, p, s, f in itertools.product(args.ry, args.pf, args.swz, args.fuse)]
             elif v == 2:
-                cfgs += [dict(variant=2, rows_per_chunk=r, prefetch=0, xcd_swizzle=s)
+                cfgs += [dict(variant=2, rows_per_chunk=r, prefetch=0, xcd_swizzle=s, fuse=0)
                          for r, s in itertools.product(args.ry, args.swz)]
             else:
-                cfgs += [dict(variant=3, rows_per_chunk=0, prefetch=0, xcd_swizzle=1)]
+                cfgs += [dict(variant=3, rows_per_chunk=0, prefetch=0, xcd_swizzle=1, fuse=0)]
         best = {}
         for rnd in range(args.rounds):
             for ci, cfg in enumerate(cfgs):
                 for k, val in cfg.items():
                     st.set_option(k, val)
-                st.run(0.05, 0.1, 0.5, 0.25, 2)
+                st.run(0.05, 0.1, 0.5, 0.25, 3)
                 st.sync()
                 st.reset_timers()
                 st.run(0.05, 0.1, 0.5, 0.25, args.steps)
-                ms, cnt = st.kernel_time()
-                per = ms / cnt
+                ms, cnt, nst = st.kernel_time()
+                per = ms / nst  # ms per time step
                 best.setdefault(ci, []).append(per)
         for ci, cfg in enumerate(cfgs):
             ts = sorted(best[ci])
