@@ -121,12 +121,14 @@ def lib() -> C.CDLL:
         "csim_stepper_download_interior": (i, [vp, dp]),
         "csim_stepper_init_gaussian": (i, [vp, d, d, d, d]),
         "csim_stepper_exchange_halos": (i, [vp]),
+        "csim_stepper_halo_pack": (i, [vp, C.POINTER(dp)]),
+        "csim_stepper_halo_unpack": (i, [vp, C.POINTER(dp)]),
         "csim_stepper_run": (i, [vp, d, d, d, d, i]),
         "csim_stepper_sync": (i, [vp]),
         "csim_stepper_minmax": (i, [vp, dp]),
         "csim_stepper_sum": (i, [vp, dp]),
         "csim_stepper_set_option": (i, [vp, C.c_char_p, C.c_long]),
-        "csim_stepper_kernel_time": (i, [vp, dp, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
+        "csim_stepper_kernel_time": (i, [vp, i, dp, C.POINTER(C.c_long)]),
         "csim_stepper_reset_timers": (i, [vp]),
     }
     for name, (res, args) in sig.items():
@@ -328,6 +330,24 @@ class Stepper:
     def exchange_halos(self):
         _ck(lib().csim_stepper_exchange_halos(self._h))
 
+    def _side_len(self, k):
+        return self.ny if k < 2 else self.nx
+
+    def halo_pack(self):
+        """edge lines of the current field per side (None on physical sides)."""
+        bufs = [np.empty(self._side_len(k)) if self.dec.nbr[k] >= 0 else None for k in range(4)]
+        arr = (C.POINTER(C.c_double) * 4)(*[_dp(b) if b is not None else None for b in bufs])
+        _ck(lib().csim_stepper_halo_pack(self._h, arr))
+        return bufs
+
+    def halo_unpack(self, lines):
+        """stage the neighbours' edge lines (list of 4, None on physical sides)."""
+        keep = [np.ascontiguousarray(b, dtype=np.float64) if b is not None else None for b in lines]
+        for k, b in enumerate(keep):
+            assert b is None or b.shape == (self._side_len(k),)
+        arr = (C.POINTER(C.c_double) * 4)(*[_dp(b) if b is not None else None for b in keep])
+        _ck(lib().csim_stepper_halo_unpack(self._h, arr))
+
     def run(self, D, dt, vx, vy, nsteps):
         _ck(lib().csim_stepper_run(self._h, D, dt, vx, vy, nsteps))
 
@@ -347,10 +367,17 @@ class Stepper:
     def set_option(self, key: str, value: int):
         _ck(lib().csim_stepper_set_option(self._h, key.encode(), int(value)))
 
-    def kernel_time(self):
-        ms, n, st = C.c_double(), C.c_long(), C.c_long()
-        _ck(lib().csim_stepper_kernel_time(self._h, C.byref(ms), C.byref(n), C.byref(st)))
-        return ms.value, n.value, st.value
+    def kernel_time(self, steps_per_launch=None):
+        """(total ms, launches) of the timed sweep launches of one kind (1 or 2 steps per launch);
+        with None: (total ms, launches, time steps covered) over both kinds."""
+        def one(t):
+            ms, n = C.c_double(), C.c_long()
+            _ck(lib().csim_stepper_kernel_time(self._h, t, C.byref(ms), C.byref(n)))
+            return ms.value, n.value
+        if steps_per_launch is not None:
+            return one(steps_per_launch)
+        (m1, n1), (m2, n2) = one(1), one(2)
+        return m1 + m2, n1 + n2, n1 + 2 * n2
 
     def reset_timers(self):
         _ck(lib().csim_stepper_reset_timers(self._h))

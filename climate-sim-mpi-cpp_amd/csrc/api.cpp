@@ -127,13 +127,13 @@ struct csim_stepper {
     SweepCfg cfg;
     int overlap = 1;
     int fuse = 1;  // two time steps per HBM pass where the kernel supports it
+    int external = 0;  // halos are carried by the caller (csim_stepper_halo_pack/_unpack), not RCCL
     int profile = 0;
     std::vector<hipEvent_t> ev_pool;  // start/stop pairs around sweep launches
     std::vector<int> ev_steps;        // time steps covered by each timed launch
     size_t ev_used = 0;
-    double prof_ms = 0.0;
-    long prof_launches = 0;
-    long prof_steps = 0;
+    double prof_ms[3]{0.0, 0.0, 0.0};   // indexed by time steps per launch (1 or 2)
+    long prof_launches[3]{0, 0, 0};
     size_t bytes() const { return sizeof(double) * static_cast<size_t>(ny + 4) * pitch; }
     // whole-allocation pointer of a view
     double* base(double* view) const { return view - pitch; }
@@ -534,6 +534,38 @@ static GhostArgs ghost_args(const csim_stepper* s) {
     return g;
 }
 
+// External transport (e.g. the reference's own MPI): the caller moves the edge lines between
+// ranks.  pack: edge lines of the current field -> host buffers (ny doubles for left/right, nx
+// for bottom/top; entries of physical sides are ignored).  unpack: the neighbours' lines -> the
+// staging buffers the next step's ghost fill reads.
+int csim_stepper_halo_pack(csim_stepper* s, double* const host_send[4]) {
+    CSIM_REQUIRE(s && host_send, "null argument");
+    if (!s->multi) return CSIM_OK;
+    CSIM_HIP(launch_pack(s->cur, s->nx, s->ny, s->pitch, s->send, s->s_comp));
+    for (int k = 0; k < 4; ++k) {
+        if (s->phys[k]) continue;
+        CSIM_REQUIRE(host_send[k], "missing host buffer for a neighbour side");
+        const size_t n = sizeof(double) * static_cast<size_t>(k < 2 ? s->ny : s->nx);
+        CSIM_HIP(hipMemcpyAsync(host_send[k], s->send[k], n, hipMemcpyDeviceToHost, s->s_comp));
+    }
+    CSIM_HIP(hipStreamSynchronize(s->s_comp));
+    return CSIM_OK;
+}
+
+int csim_stepper_halo_unpack(csim_stepper* s, const double* const host_recv[4]) {
+    CSIM_REQUIRE(s && host_recv, "null argument");
+    if (!s->multi) return CSIM_OK;
+    for (int k = 0; k < 4; ++k) {
+        if (s->phys[k]) continue;
+        CSIM_REQUIRE(host_recv[k], "missing host buffer for a neighbour side");
+        const size_t n = sizeof(double) * static_cast<size_t>(k < 2 ? s->ny : s->nx);
+        CSIM_HIP(hipMemcpyAsync(s->recv[k], host_recv[k], n, hipMemcpyHostToDevice, s->s_comp));
+    }
+    CSIM_HIP(hipStreamSynchronize(s->s_comp));
+    s->halo_fresh = true;
+    return CSIM_OK;
+}
+
 int csim_stepper_exchange_halos(csim_stepper* s) {
     CSIM_REQUIRE(s, "null stepper");
     if (!s->multi) return CSIM_OK;
@@ -554,9 +586,9 @@ static int prof_fold(csim_stepper* s) {
     for (size_t k = 0; k + 1 < s->ev_used; k += 2) {
         float ms = 0.f;
         CSIM_HIP(hipEventElapsedTime(&ms, s->ev_pool[k], s->ev_pool[k + 1]));
-        s->prof_ms += ms;
-        s->prof_launches += 1;
-        s->prof_steps += s->ev_steps[k / 2];
+        const int t = s->ev_steps[k / 2];
+        s->prof_ms[t] += ms;
+        s->prof_launches[t] += 1;
     }
     s->ev_used = 0;
     return CSIM_OK;
@@ -565,8 +597,15 @@ static int prof_fold(csim_stepper* s) {
 int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy, int nsteps) {
     CSIM_REQUIRE(s, "null stepper");
     CSIM_REQUIRE(nsteps >= 0, "nsteps must be >= 0");
-    if (s->multi && !s->comm)
+    if (s->multi && s->external) {
+        if (nsteps > 1)
+            return fail(CSIM_ERR_STATE, "external halo transport advances one step per call");
+        if (nsteps == 1 && !s->halo_fresh)
+            return fail(CSIM_ERR_STATE, "external halo transport: csim_stepper_halo_unpack first");
+    } else if (s->multi && !s->comm) {
         return fail(CSIM_ERR_STATE, "multi-rank stepper needs csim_stepper_comm_init before run");
+    }
+    const bool rccl = s->multi && !s->external;
     const Phys p = make_phys(s->dx, s->dy, D, dt, vx, vy);
     const GhostArgs g = ghost_args(s);
     // Two steps per HBM pass where possible.  The LAST step of a call is always a single-step
@@ -579,7 +618,7 @@ int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy,
     int remaining = nsteps;
     while (remaining > 0) {
         const int t = (can2 && remaining >= 3) ? 2 : 1;
-        if (s->multi) {
+        if (rccl) {
             if (!s->halo_fresh) {
                 int rc = refresh_halos(s);  // on s_comp: ordered before the ghost fill
                 if (rc) return rc;
@@ -589,7 +628,7 @@ int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy,
         }
         // exchange_halos (unpack) + apply_boundary, mirrored into the partner buffer
         CSIM_HIP(launch_ghost_fill(s->cur, s->nxt, s->nx, s->ny, s->pitch, g, s->s_comp));
-        if (s->multi && s->overlap) {
+        if (rccl && s->overlap) {
             // edge lines of the NEXT field first, so their exchange overlaps the full sweep
             CSIM_HIP(launch_edge_pack(s->cur, s->nx, s->ny, s->pitch, p, s->send, s->s_comp));
             CSIM_HIP(hipEventRecord(s->ev_edge, s->s_comp));
@@ -622,7 +661,7 @@ int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy,
             s->ev_used += 2;
         }
         std::swap(s->cur, s->nxt);
-        if (s->multi && !s->overlap) s->halo_fresh = false;  // serial mode: re-exchange next step
+        if (s->multi && (s->external || !s->overlap)) s->halo_fresh = false;  // exchange again next step
         remaining -= t;
     }
     return CSIM_OK;
@@ -666,6 +705,9 @@ int csim_stepper_set_option(csim_stepper* s, const char* key, long value) {
         s->cfg.xcd_swizzle = value != 0;
     } else if (k == "overlap") {
         s->overlap = value != 0;
+    } else if (k == "external_halo") {
+        s->external = value != 0;
+        s->halo_fresh = false;
     } else if (k == "fuse") {
         s->fuse = value != 0;
     } else if (k == "profile") {
@@ -676,13 +718,14 @@ int csim_stepper_set_option(csim_stepper* s, const char* key, long value) {
     return CSIM_OK;
 }
 
-int csim_stepper_kernel_time(csim_stepper* s, double* total_ms, long* launches, long* steps) {
-    CSIM_REQUIRE(s && total_ms && launches && steps, "null argument");
+int csim_stepper_kernel_time(csim_stepper* s, int steps_per_launch, double* total_ms,
+                             long* launches) {
+    CSIM_REQUIRE(s && total_ms && launches, "null argument");
+    CSIM_REQUIRE(steps_per_launch == 1 || steps_per_launch == 2, "steps_per_launch must be 1 or 2");
     int rc = prof_fold(s);
     if (rc) return rc;
-    *total_ms = s->prof_ms;
-    *launches = s->prof_launches;
-    *steps = s->prof_steps;
+    *total_ms = s->prof_ms[steps_per_launch];
+    *launches = s->prof_launches[steps_per_launch];
     return CSIM_OK;
 }
 
@@ -690,9 +733,10 @@ int csim_stepper_reset_timers(csim_stepper* s) {
     CSIM_REQUIRE(s, "null stepper");
     int rc = prof_fold(s);
     if (rc) return rc;
-    s->prof_ms = 0.0;
-    s->prof_launches = 0;
-    s->prof_steps = 0;
+    for (int t = 0; t < 3; ++t) {
+        s->prof_ms[t] = 0.0;
+        s->prof_launches[t] = 0;
+    }
     return CSIM_OK;
 }
 

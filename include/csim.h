@@ -118,6 +118,13 @@ int csim_stepper_download_interior(csim_stepper* s, double* host_ny_by_nx);
 /* gaussian hotspot written on the device (reference src/init.cpp:12-33) */
 int csim_stepper_init_gaussian(csim_stepper* s, double A, double sigma_frac, double xc_frac,
                                double yc_frac);
+/* External halo transport (option "external_halo"=1), for callers that keep the reference's
+ * MPI exchange (src/halo.cpp:28-46) or any other carrier: pack copies the four edge lines of
+ * the current field to host buffers (ny doubles for left/right, nx for bottom/top; entries of
+ * physical sides are ignored), unpack stages the lines received from the neighbours for the
+ * next csim_stepper_run(.., 1).  One step per run call in this mode. */
+int csim_stepper_halo_pack(csim_stepper* s, double* const host_send[4]);
+int csim_stepper_halo_unpack(csim_stepper* s, const double* const host_recv[4]);
 /* reference src/halo.cpp:6-50  exchange_halos(u, dec, comm) on the current field */
 int csim_stepper_exchange_halos(csim_stepper* s);
 /* nsteps x { exchange_halos; apply_boundary; fused sweep; swap }, enqueued without host syncs */
@@ -128,11 +135,13 @@ int csim_stepper_sum(csim_stepper* s, double* out);
 /* tuning / measurement knobs; unknown keys give CSIM_ERR_ARG.
  *   "variant" kernel family (0 auto, 1 dpp, 2 lds, 3 naive), "rows_per_chunk", "prefetch",
  *   "xcd_swizzle" (0/1), "fuse" (0/1: two time steps per HBM pass), "overlap" (0/1: halo
- *   exchange on the second stream), "profile" (0/1) */
+ *   exchange on the second stream), "external_halo" (0/1), "profile" (0/1) */
 int csim_stepper_set_option(csim_stepper* s, const char* key, long value);
-/* with option "profile"=1: HIP-event time of the sweep launches since the last reset, their
- * count, and the number of time steps they covered (a fused launch covers two) */
-int csim_stepper_kernel_time(csim_stepper* s, double* total_ms, long* launches, long* steps);
+/* with option "profile"=1: HIP-event time (on the compute stream) and count of the sweep
+ * launches since the last reset, per kernel kind: steps_per_launch = 2 selects the fused
+ * two-steps-per-pass kernel, 1 the single-step kernel */
+int csim_stepper_kernel_time(csim_stepper* s, int steps_per_launch, double* total_ms,
+                             long* launches);
 int csim_stepper_reset_timers(csim_stepper* s);
 
 #ifdef __cplusplus

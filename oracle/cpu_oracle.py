@@ -45,6 +45,7 @@ def lib() -> C.CDLL:
         L.ora_apply_boundary.argtypes = [dp, C.c_int, C.c_int, ip, ip, C.c_double]
         L.ora_diffusion_step.argtypes = [dp, dp, C.c_int, C.c_int] + [C.c_double] * 4
         L.ora_advection_step.argtypes = [dp, dp, C.c_int, C.c_int] + [C.c_double] * 5
+        L.ora_step_tile.argtypes = [dp, dp, C.c_int, C.c_int] + [C.c_double] * 6 + [ip, ip]
         L.ora_run_single.argtypes = [dp, C.c_int, C.c_int] + [C.c_double] * 6 + [ip, C.c_int]
         L.ora_dims_create.argtypes = [C.c_int, ip]
         L.ora_decomp.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, ip]
@@ -95,6 +96,12 @@ def diffusion_step(u, out, dx, dy, D, dt) -> None:
 def advection_step(u, out, dx, dy, vx, vy, dt) -> None:
     ny, nx = u.shape[0] - 2, u.shape[1] - 2
     lib().ora_advection_step(_dp(u), _dp(out), nx, ny, dx, dy, vx, vy, dt)
+
+
+def step_tile(u, tmp, dx, dy, D, vx, vy, dt, bc, phys) -> None:
+    """boundary (physical sides only) -> copy -> diffusion -> advection; result in tmp."""
+    ny, nx = u.shape[0] - 2, u.shape[1] - 2
+    lib().ora_step_tile(_dp(u), _dp(tmp), nx, ny, dx, dy, D, vx, vy, dt, _i4(bc), _i4(phys))
 
 
 def run_single(u, dx, dy, D, vx, vy, dt, bc, steps) -> None:

@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""tests/multirank_worker.py — one rank of an N-rank run of the hot path (launched by
+tests/test_multirank_gloo.py / tests/test_gpu_multirank.py through torch.distributed.run).
+
+The decomposition always comes from the PRODUCT (csim_decomp_init in libcsim.so); halos travel
+over torch.distributed gloo point-to-point messages posted in the order of reference
+src/halo.cpp:28-43.  Two engines step the local tile:
+  --engine oracle        CPU: oracle/cpu_stepper.c (tests the N>1 host logic without a GPU)
+  --engine hip-external  GPU: the HIP stepper with csim_stepper_halo_pack/_unpack
+                         (several ranks may share one GPU; RCCL refuses that, gloo does not)
+Rank 0 gathers the global interior and compares it bit-for-bit with the golden fixture."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+from oracle import cpu_oracle as ora  # noqa: E402
+
+OPPOSITE = {0: 1, 1: 0, 2: 3, 3: 2}
+
+
+def exchange(lines, nbr):
+    """send my edge line of side k to nbr[k]; receive the neighbour's (its opposite side)."""
+    reqs, got = [], [None] * 4
+    for k in range(4):
+        if nbr[k] >= 0:
+            got[k] = torch.empty(lines[k].shape[0], dtype=torch.float64)
+            reqs.append(dist.irecv(got[k], src=nbr[k], tag=OPPOSITE[k]))
+    for k in range(4):
+        if nbr[k] >= 0:
+            reqs.append(dist.isend(torch.from_numpy(np.ascontiguousarray(lines[k])), dst=nbr[k], tag=k))
+    for r in reqs:
+        r.wait()
+    return [g.numpy() if g is not None else None for g in got]
+
+
+def edges(u, nbr):
+    return [u[1:-1, 1].copy() if nbr[0] >= 0 else None, u[1:-1, -2].copy() if nbr[1] >= 0 else None,
+            u[1, 1:-1].copy() if nbr[2] >= 0 else None, u[-2, 1:-1].copy() if nbr[3] >= 0 else None]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--engine", default="oracle")
+    ap.add_argument("--case", required=True, help="path of a tests/golden/run_*.npz fixture")
+    args = ap.parse_args()
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    csim = load_package()
+    z = np.load(args.case, allow_pickle=False)
+    m = json.loads(str(z["meta"]))
+    dt = float(z["dt_effective"])
+    dec = csim.decomp_init(world, rank, m["nx"], m["ny"])
+    want_dec = z[f"decomp_np{world}"][rank]
+    assert list(dec.as_dict().values()) == list(want_dec), "decomposition differs from MPI's"
+    nbr = list(dec.nbr)
+    phys = [1 if n < 0 else 0 for n in nbr]
+    bc = csim.bc_codes(m["bc"])
+    u = np.zeros((dec.ny_local + 2, dec.nx_local + 2))
+    u[1:-1, 1:-1] = z["u0"][dec.y_offset:dec.y_offset + dec.ny_local,
+                            dec.x_offset:dec.x_offset + dec.nx_local]
+
+    if args.engine == "oracle":
+        tmp = u.copy()
+        for _ in range(m["steps"]):
+            got = exchange(edges(u, nbr), nbr)
+            if got[0] is not None:
+                u[1:-1, 0] = got[0]
+            if got[1] is not None:
+                u[1:-1, -1] = got[1]
+            if got[2] is not None:
+                u[0, 1:-1] = got[2]
+            if got[3] is not None:
+                u[-1, 1:-1] = got[3]
+            ora.step_tile(u, tmp, m["dx"], m["dy"], m["D"], m["vx"], m["vy"], dt, bc, phys)
+            u, tmp = tmp, u
+        local = u
+    elif args.engine == "hip-external":
+        csim.lib()
+        csim.set_device(0)
+        st = csim.Stepper(dec, m["dx"], m["dy"], bc)
+        st.set_option("external_halo", 1)
+        st.upload(u)
+        for _ in range(m["steps"]):
+            st.halo_unpack(exchange(st.halo_pack(), nbr))
+            st.run(m["D"], dt, m["vx"], m["vy"], 1)
+        local = st.download()
+        st.close()
+    else:
+        raise SystemExit("unknown engine")
+
+    # per-rank full local array (ghosts included, corners excluded: SURVEY Q7)
+    want_local = z[f"local_np{world}_rank{rank}"]
+    mask = np.ones(local.shape, bool)
+    if world > 1:
+        mask[[0, 0, -1, -1], [0, -1, 0, -1]] = False
+    ok_local = bool(np.array_equal(local[mask], want_local[mask]))
+    parts = [None] * world
+    dist.all_gather_object(parts, (dec.x_offset, dec.y_offset, local[1:-1, 1:-1].copy(), ok_local))
+    ok = True
+    if rank == 0:
+        glob = np.zeros((m["ny"], m["nx"]))
+        for xo, yo, a, okl in parts:
+            glob[yo:yo + a.shape[0], xo:xo + a.shape[1]] = a
+            ok = ok and okl
+        ok = ok and bool(np.array_equal(glob, z["u_final"]))
+        print(f"MULTIRANK engine={args.engine} world={world} case={os.path.basename(args.case)} ok={ok}",
+              flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()

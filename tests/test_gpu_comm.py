@@ -1,0 +1,101 @@
+"""The RCCL halo-exchange path on ONE GPU.  A 1-rank communicator whose four neighbours are
+the rank itself turns the tile into a true torus, which drives every piece of the multi-GPU
+step — edge-pack kernel, grouped ncclSend/ncclRecv on the second stream, event hand-off, unpack
+in the ghost fill, overlap on/off — through real RCCL calls.  (The reference itself never
+wraps; the torus is only the cheapest way to exercise the exchange on one device.
+Multi-rank decomposition logic is covered on CPU by tests/test_multirank_gloo.py.)"""
+import numpy as np
+import pytest
+
+from __graft_entry__ import load_package
+from oracle import cpu_oracle as ora
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def csim():
+    pkg = load_package()
+    pkg.lib()
+    pkg.set_device(0)
+    return pkg
+
+
+def torus_oracle(u0, dx, dy, D, vx, vy, dt, steps, sides=(1, 1, 1, 1), bc=(0, 0, 0, 0)):
+    """reference step with the ghosts of the `sides` flagged 1 wrapped from the opposite edge
+    (what exchange_halos delivers when the neighbour is the rank itself)."""
+    u = u0.copy()
+    tmp = u0.copy()
+    phys = [0 if s else 1 for s in sides]
+    for _ in range(steps):
+        if sides[0]:
+            u[1:-1, 0] = u[1:-1, -2]
+        if sides[1]:
+            u[1:-1, -1] = u[1:-1, 1]
+        if sides[2]:
+            u[0, 1:-1] = u[-2, 1:-1]
+        if sides[3]:
+            u[-1, 1:-1] = u[1, 1:-1]
+        ora.step_tile(u, tmp, dx, dy, D, vx, vy, dt, bc, phys)
+        u, tmp = tmp, u
+    return u
+
+
+def self_neighbor_decomp(csim, nx, ny, sides):
+    d = csim.decomp_init(1, 0, nx, ny)
+    for k in range(4):
+        d.nbr[k] = 0 if sides[k] else csim.NO_NEIGHBOR
+    return d
+
+
+# neighbour links come in opposite pairs (if A's left is B, B's right is A), so the self-linked
+# sides are {left,right} and/or {bottom,top}
+@pytest.mark.parametrize("sides,bc", [((1, 1, 1, 1), "dddd"), ((1, 1, 0, 0), "ddnd"),
+                                      ((0, 0, 1, 1), "npdd"), ((1, 1, 0, 0), "ddpp")])
+@pytest.mark.parametrize("overlap", [1, 0])
+def test_self_exchange_torus(csim, sides, bc, overlap):
+    nx, ny, steps = 300, 170, 7
+    D, vx, vy, dt = 0.05, 0.5, -0.25, 0.1
+    rng = np.random.default_rng(17)
+    u0 = np.zeros((ny + 2, nx + 2))
+    u0[1:-1, 1:-1] = rng.standard_normal((ny, nx))
+    codes = csim.bc_codes(bc)
+    want = torus_oracle(u0, 1.0, 1.0, D, vx, vy, dt, steps, sides, codes)
+
+    st = csim.Stepper(self_neighbor_decomp(csim, nx, ny, sides), 1.0, 1.0, codes)
+    st.comm_init(csim.comm_unique_id())
+    st.set_option("overlap", overlap)
+    st.upload(u0)
+    st.run(D, dt, vx, vy, 3)
+    st.run(D, dt, vx, vy, steps - 3)
+    got = st.download()
+    st.close()
+    # corners are never exchanged (reference leaves them undefined)
+    mask = np.ones(got.shape, bool)
+    mask[[0, 0, -1, -1], [0, -1, 0, -1]] = False
+    assert np.array_equal(got[mask], want[mask]), float(np.abs(got - want)[mask].max())
+
+
+def test_exchange_halos_alone(csim):
+    """reference tests/simulation/unit/test_halo.cpp:36-56 restated: after exchange_halos every
+    ghost face on a neighbour side holds the neighbour's edge cells, physical sides untouched."""
+    nx, ny = 40, 24
+    rng = np.random.default_rng(4)
+    u0 = np.full((ny + 2, nx + 2), -1.0)
+    u0[1:-1, 1:-1] = rng.random((ny, nx))
+    st = csim.Stepper(self_neighbor_decomp(csim, nx, ny, (1, 1, 0, 0)), 1.0, 1.0, csim.bc_codes("dddd"))
+    st.comm_init(csim.comm_unique_id())
+    st.upload(u0)
+    st.exchange_halos()
+    g = st.download()
+    st.close()
+    assert np.array_equal(g[1:-1, 0], u0[1:-1, -2]) and np.array_equal(g[1:-1, -1], u0[1:-1, 1])
+    assert (g[0, :] == -1.0).all() and (g[-1, :] == -1.0).all()  # no y-neighbours: untouched
+    assert np.array_equal(g[1:-1, 1:-1], u0[1:-1, 1:-1])
+
+
+def test_multi_rank_run_needs_comm(csim):
+    st = csim.Stepper(self_neighbor_decomp(csim, 16, 16, (1, 0, 0, 0)), 1.0, 1.0, [0, 0, 0, 0])
+    with pytest.raises(csim.CsimError):
+        st.run(0.1, 0.1, 0.0, 0.0, 1)
+    st.close()
