@@ -1,0 +1,82 @@
+// include/climate/stepper.hpp — the time loop of reference src/main.cpp:93-118 on the GPU.
+//
+// Replaces, per step,  exchange_halos(u,dec,comm); apply_boundary(u,dec,bc,0.0);
+//                      std::copy(u -> tmp); diffusion_step(u,tmp,D,dt);
+//                      advection_step(u,tmp,vx,vy,dt); std::swap(u.data,tmp.data);
+// by  stepper.run(D, dt, vx, vy, nsteps)  with the field resident in HBM.  Host `Field`s are
+// only touched by upload()/download() (the snapshot point, reference src/io.cpp:402-424).
+// Errors surface as std::runtime_error carrying csim_last_error().
+#pragma once
+#include <stdexcept>
+#include <string>
+
+#include "boundary.hpp"
+#include "csim.h"
+#include "decomp.hpp"
+#include "field.hpp"
+
+namespace climate {
+
+inline void check(int rc) {
+    if (rc != CSIM_OK) throw std::runtime_error(std::string("csim: ") + csim_last_error());
+}
+
+inline int bc_code(BCType t) {
+    return t == BCType::Dirichlet ? CSIM_BC_DIRICHLET : t == BCType::Neumann ? CSIM_BC_NEUMANN : CSIM_BC_PERIODIC;
+}
+
+class Stepper {
+  public:
+    Stepper(const Decomp2D& dec, const BCConfig& bc, double dx, double dy, double bc_value = 0.0) {
+        const csim_decomp d = dec.c_abi();
+        const int codes[4] = {bc_code(bc.left), bc_code(bc.right), bc_code(bc.bottom), bc_code(bc.top)};
+        check(csim_stepper_create(&d, dx, dy, codes, bc_value, &h_));
+    }
+    ~Stepper() { csim_stepper_destroy(h_); }
+    Stepper(const Stepper&) = delete;
+    Stepper& operator=(const Stepper&) = delete;
+
+    // multi-GPU: RCCL communicator; `id` = CSIM_UNIQUE_ID_BYTES made by rank 0 (unique_id()) and
+    // broadcast by the launcher's means (MPI_Bcast in an MPI build: connect(comm) below)
+    static void unique_id(void* id) { check(csim_comm_unique_id(id, CSIM_UNIQUE_ID_BYTES)); }
+    void connect_with_id(const void* id) { check(csim_stepper_comm_init(h_, id, CSIM_UNIQUE_ID_BYTES)); }
+#ifdef CSIM_WITH_MPI
+    void connect(MPI_Comm comm) {
+        unsigned char id[CSIM_UNIQUE_ID_BYTES];
+        int rank = 0;
+        MPI_Comm_rank(comm, &rank);
+        if (rank == 0) unique_id(id);
+        MPI_Bcast(id, CSIM_UNIQUE_ID_BYTES, MPI_BYTE, 0, comm);
+        connect_with_id(id);
+    }
+#endif
+
+    void upload(const Field& u) { check(csim_stepper_upload(h_, u.data.data())); }
+    void download(Field& u) { check(csim_stepper_download(h_, u.data.data())); }
+    void download_interior(double* ny_by_nx) { check(csim_stepper_download_interior(h_, ny_by_nx)); }
+    void init_gaussian(double A, double sigma_frac, double xc_frac, double yc_frac) {
+        check(csim_stepper_init_gaussian(h_, A, sigma_frac, xc_frac, yc_frac));
+    }
+    void run(double D, double dt, double vx, double vy, int nsteps) {
+        check(csim_stepper_run(h_, D, dt, vx, vy, nsteps));
+    }
+    void sync() { check(csim_stepper_sync(h_)); }
+    void set_option(const char* key, long v) { check(csim_stepper_set_option(h_, key, v)); }
+    void minmax(double& mn, double& mx) {
+        double o[2];
+        check(csim_stepper_minmax(h_, o));
+        mn = o[0];
+        mx = o[1];
+    }
+    double sum() {
+        double s = 0;
+        check(csim_stepper_sum(h_, &s));
+        return s;
+    }
+    csim_stepper* handle() { return h_; }
+
+  private:
+    csim_stepper* h_ = nullptr;
+};
+
+}  // namespace climate
