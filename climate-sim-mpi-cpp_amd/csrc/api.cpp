@@ -124,6 +124,13 @@ struct csim_stepper {
     ncclComm_t comm = nullptr;
     bool multi = false;       // has at least one neighbour
     bool halo_fresh = false;  // recv[] holds the neighbours' edge lines of `cur`
+    // depth-2 faces for two-steps-per-pass on several ranks; directions L R B T BL BR TL TR
+    int nbr8[8]{-1, -1, -1, -1, -1, -1, -1, -1};
+    size_t len2[8]{0, 0, 0, 0, 0, 0, 0, 0};
+    double* send2[8]{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double* recv2[8]{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_edge2 = nullptr, ev_recv2 = nullptr;
+    bool halo2_fresh = false;  // recv2[] holds the neighbours' depth-2 faces of `cur`
     SweepCfg cfg;
     int overlap = 1;
     int fuse = 1;  // two time steps per HBM pass where the kernel supports it
@@ -396,6 +403,31 @@ int csim_stepper_create(const csim_decomp* dec, double dx, double dy, const int 
             ok(hipMalloc(reinterpret_cast<void**>(&s->recv[k]), n)) &&
             ok(hipMemset(s->send[k], 0, n)) && ok(hipMemset(s->recv[k], 0, n));
     }
+    // diagonal peers (only where both adjacent sides have neighbours)
+    for (int k = 0; k < 4; ++k) s->nbr8[k] = dec->nbr[k];
+    {
+        const int cx = dec->coords[0], cy = dec->coords[1], py = dec->dims[1];
+        auto diag = [&](int sx, int sy, int dx_, int dy_) {
+            if (dec->nbr[sx] < 0 || dec->nbr[sy] < 0) return -1;
+            return dec->size == 1 ? 0 : (cx + dx_) * py + (cy + dy_);
+        };
+        s->nbr8[4] = diag(CSIM_LEFT, CSIM_BOTTOM, -1, -1);
+        s->nbr8[5] = diag(CSIM_RIGHT, CSIM_BOTTOM, +1, -1);
+        s->nbr8[6] = diag(CSIM_LEFT, CSIM_TOP, -1, +1);
+        s->nbr8[7] = diag(CSIM_RIGHT, CSIM_TOP, +1, +1);
+    }
+    for (int d = 0; d < 8 && e == hipSuccess; ++d) {
+        if (s->nbr8[d] < 0) continue;
+        s->len2[d] = d < 2 ? 2 * static_cast<size_t>(s->ny) : d < 4 ? 2 * static_cast<size_t>(s->nx + 2) : 4;
+        const size_t n = sizeof(double) * s->len2[d];
+        ok(hipMalloc(reinterpret_cast<void**>(&s->send2[d]), n)) &&
+            ok(hipMalloc(reinterpret_cast<void**>(&s->recv2[d]), n)) &&
+            ok(hipMemset(s->send2[d], 0, n)) && ok(hipMemset(s->recv2[d], 0, n));
+    }
+    if (e == hipSuccess) {
+        ok(hipEventCreateWithFlags(&s->ev_edge2, hipEventDisableTiming)) &&
+            ok(hipEventCreateWithFlags(&s->ev_recv2, hipEventDisableTiming));
+    }
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) {
         s->cur = s->buf[0] + s->pitch;
@@ -419,6 +451,12 @@ int csim_stepper_destroy(csim_stepper* s) {
         if (s->send[k]) (void)hipFree(s->send[k]);
         if (s->recv[k]) (void)hipFree(s->recv[k]);
     }
+    for (int d = 0; d < 8; ++d) {
+        if (s->send2[d]) (void)hipFree(s->send2[d]);
+        if (s->recv2[d]) (void)hipFree(s->recv2[d]);
+    }
+    if (s->ev_edge2) (void)hipEventDestroy(s->ev_edge2);
+    if (s->ev_recv2) (void)hipEventDestroy(s->ev_recv2);
     if (s->ev_edge) (void)hipEventDestroy(s->ev_edge);
     if (s->ev_recv) (void)hipEventDestroy(s->ev_recv);
     if (s->s_comp) (void)hipStreamDestroy(s->s_comp);
@@ -462,6 +500,7 @@ int csim_stepper_upload(csim_stepper* s, const double* host) {
                             s->s_comp));
     CSIM_HIP(hipStreamSynchronize(s->s_comp));
     s->halo_fresh = false;
+    s->halo2_fresh = false;
     return CSIM_OK;
 }
 
@@ -489,6 +528,7 @@ int csim_stepper_init_gaussian(csim_stepper* s, double A, double sigma_frac, dou
                             s->s_comp));
     CSIM_HIP(hipStreamSynchronize(s->s_comp));
     s->halo_fresh = false;
+    s->halo2_fresh = false;
     return CSIM_OK;
 }
 
@@ -509,6 +549,26 @@ static int post_exchange(csim_stepper* s, hipStream_t st) {
         if (s->phys[k]) continue;
         const size_t n = static_cast<size_t>(k < 2 ? s->ny : s->nx);
         CSIM_NCCL(ncclRecv(s->recv[k], n, ncclDouble, s->dec.nbr[k], s->comm, st));
+    }
+    CSIM_NCCL(ncclGroupEnd());
+    return CSIM_OK;
+}
+
+// the same for the depth-2 faces of the two-steps-per-pass sweep: up to 8 peers in ONE group
+// (diagonal ranks are direct xGMI peers too).  Sends go out in direction order, receives are
+// posted in opposite-direction order, so per-peer message order matches even when one peer sits
+// in several directions (a 2-wide process grid, or the self-linked test torus).
+static int post_exchange2(csim_stepper* s, hipStream_t st) {
+    if (!s->comm) return fail(CSIM_ERR_STATE, "halo exchange needs csim_stepper_comm_init first");
+    static const int recv_order[8] = {1, 0, 3, 2, 7, 6, 5, 4};
+    CSIM_NCCL(ncclGroupStart());
+    for (int d = 0; d < 8; ++d)
+        if (s->nbr8[d] >= 0)
+            CSIM_NCCL(ncclSend(s->send2[d], s->len2[d], ncclDouble, s->nbr8[d], s->comm, st));
+    for (int q = 0; q < 8; ++q) {
+        const int d = recv_order[q];
+        if (s->nbr8[d] >= 0)
+            CSIM_NCCL(ncclRecv(s->recv2[d], s->len2[d], ncclDouble, s->nbr8[d], s->comm, st));
     }
     CSIM_NCCL(ncclGroupEnd());
     return CSIM_OK;
@@ -566,6 +626,44 @@ int csim_stepper_halo_unpack(csim_stepper* s, const double* const host_recv[4]) 
     return CSIM_OK;
 }
 
+// depth-2 flavour of the external transport, for csim_stepper_run(.., 2) in external mode
+int csim_stepper_halo2_neighbors(const csim_stepper* s, int peers[8], int lengths[8]) {
+    CSIM_REQUIRE(s && peers && lengths, "null argument");
+    for (int d = 0; d < 8; ++d) {
+        peers[d] = s->nbr8[d];
+        lengths[d] = static_cast<int>(s->len2[d]);
+    }
+    return CSIM_OK;
+}
+
+int csim_stepper_halo2_pack(csim_stepper* s, double* const host_send[8]) {
+    CSIM_REQUIRE(s && host_send, "null argument");
+    if (!s->multi) return CSIM_OK;
+    CSIM_HIP(launch_halo2_pack(s->cur, s->nx, s->ny, s->pitch, s->send2, s->s_comp));
+    for (int d = 0; d < 8; ++d) {
+        if (s->nbr8[d] < 0) continue;
+        CSIM_REQUIRE(host_send[d], "missing host buffer for a neighbour direction");
+        CSIM_HIP(hipMemcpyAsync(host_send[d], s->send2[d], sizeof(double) * s->len2[d],
+                                hipMemcpyDeviceToHost, s->s_comp));
+    }
+    CSIM_HIP(hipStreamSynchronize(s->s_comp));
+    return CSIM_OK;
+}
+
+int csim_stepper_halo2_unpack(csim_stepper* s, const double* const host_recv[8]) {
+    CSIM_REQUIRE(s && host_recv, "null argument");
+    if (!s->multi) return CSIM_OK;
+    for (int d = 0; d < 8; ++d) {
+        if (s->nbr8[d] < 0) continue;
+        CSIM_REQUIRE(host_recv[d], "missing host buffer for a neighbour direction");
+        CSIM_HIP(hipMemcpyAsync(s->recv2[d], host_recv[d], sizeof(double) * s->len2[d],
+                                hipMemcpyHostToDevice, s->s_comp));
+    }
+    CSIM_HIP(hipStreamSynchronize(s->s_comp));
+    s->halo2_fresh = true;
+    return CSIM_OK;
+}
+
 int csim_stepper_exchange_halos(csim_stepper* s) {
     CSIM_REQUIRE(s, "null stepper");
     if (!s->multi) return CSIM_OK;
@@ -594,75 +692,144 @@ static int prof_fold(csim_stepper* s) {
     return CSIM_OK;
 }
 
+static int prof_begin(csim_stepper* s, int steps) {
+    constexpr size_t POOL = 2048;
+    if (!s->profile) return CSIM_OK;
+    if (s->ev_used + 2 > POOL) {
+        int rc = prof_fold(s);
+        if (rc) return rc;
+    }
+    while (s->ev_pool.size() < s->ev_used + 2) {
+        hipEvent_t ev;
+        CSIM_HIP(hipEventCreate(&ev));
+        s->ev_pool.push_back(ev);
+    }
+    if (s->ev_steps.size() < s->ev_pool.size() / 2) s->ev_steps.resize(s->ev_pool.size() / 2);
+    s->ev_steps[s->ev_used / 2] = steps;
+    CSIM_HIP(hipEventRecord(s->ev_pool[s->ev_used], s->s_comp));
+    return CSIM_OK;
+}
+
+static int prof_end(csim_stepper* s) {
+    if (!s->profile) return CSIM_OK;
+    CSIM_HIP(hipEventRecord(s->ev_pool[s->ev_used + 1], s->s_comp));
+    s->ev_used += 2;
+    return CSIM_OK;
+}
+
+// ONE reference step: exchange_halos + apply_boundary + fused sweep + swap
+static int pass_single(csim_stepper* s, const Phys& p, const GhostArgs& g) {
+    const bool rccl = s->multi && !s->external;
+    if (rccl) {
+        if (!s->halo_fresh) {
+            int rc = refresh_halos(s);  // on s_comp: ordered before the ghost fill
+            if (rc) return rc;
+        } else if (s->overlap) {
+            CSIM_HIP(hipStreamWaitEvent(s->s_comp, s->ev_recv, 0));
+        }
+    }
+    // exchange_halos (unpack) + apply_boundary, mirrored into the partner buffer
+    CSIM_HIP(launch_ghost_fill(s->cur, s->nxt, s->nx, s->ny, s->pitch, g, s->s_comp));
+    if (rccl && s->overlap) {
+        // edge lines of the NEXT field first, so their exchange overlaps the full sweep
+        CSIM_HIP(launch_edge_pack(s->cur, s->nx, s->ny, s->pitch, p, s->send, s->s_comp));
+        CSIM_HIP(hipEventRecord(s->ev_edge, s->s_comp));
+        CSIM_HIP(hipStreamWaitEvent(s->s_comm, s->ev_edge, 0));
+        int rc = post_exchange(s, s->s_comm);
+        if (rc) return rc;
+        CSIM_HIP(hipEventRecord(s->ev_recv, s->s_comm));
+    }
+    int rc = prof_begin(s, 1);
+    if (rc) return rc;
+    CSIM_HIP(launch_sweep(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, s->cfg, s->s_comp));
+    rc = prof_end(s);
+    if (rc) return rc;
+    std::swap(s->cur, s->nxt);
+    if (s->multi && (s->external || !s->overlap)) s->halo_fresh = false;  // exchange again next step
+    s->halo2_fresh = false;
+    return CSIM_OK;
+}
+
+// TWO reference steps in one HBM pass.  Several ranks: depth-2 faces (8 directions) are staged
+// in recv2[]; when the next pass is fused too, the frame tiles are computed first, their faces
+// packed and sent on the comm stream, and the exchange overlaps the rest of the sweep.
+static int pass_fused(csim_stepper* s, const Phys& p, bool next_fused) {
+    const bool rccl = s->multi && !s->external;
+    int kind2[4];
+    for (int k = 0; k < 4; ++k) kind2[k] = s->phys[k] ? s->bc[k] : 3;
+    GhostArgs g = ghost_args(s);
+    for (int k = 0; k < 4; ++k) g.recv[k] = nullptr;  // neighbour sides come from the depth-2 faces
+    if (s->multi) {
+        if (!s->halo2_fresh) {
+            if (s->external)
+                return fail(CSIM_ERR_STATE, "external halo transport: csim_stepper_halo2_unpack first");
+            CSIM_HIP(launch_halo2_pack(s->cur, s->nx, s->ny, s->pitch, s->send2, s->s_comp));
+            int rc = post_exchange2(s, s->s_comp);
+            if (rc) return rc;
+        } else if (rccl && s->overlap) {
+            CSIM_HIP(hipStreamWaitEvent(s->s_comp, s->ev_recv2, 0));
+        }
+        CSIM_HIP(launch_halo2_unpack(s->cur, s->nx, s->ny, s->pitch, s->recv2, s->s_comp));
+    }
+    CSIM_HIP(launch_ghost_fill(s->cur, s->nxt, s->nx, s->ny, s->pitch, g, s->s_comp));
+    int rc = prof_begin(s, 2);
+    if (rc) return rc;
+    if (rccl && s->overlap && next_fused) {
+        CSIM_HIP(launch_sweep2(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, s->cfg, kind2, s->bc_value, 1,
+                               s->s_comp));
+        CSIM_HIP(launch_halo2_pack(s->nxt, s->nx, s->ny, s->pitch, s->send2, s->s_comp));
+        CSIM_HIP(hipEventRecord(s->ev_edge2, s->s_comp));
+        CSIM_HIP(hipStreamWaitEvent(s->s_comm, s->ev_edge2, 0));
+        rc = post_exchange2(s, s->s_comm);
+        if (rc) return rc;
+        CSIM_HIP(hipEventRecord(s->ev_recv2, s->s_comm));
+        CSIM_HIP(launch_sweep2(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, s->cfg, kind2, s->bc_value, 2,
+                               s->s_comp));
+        s->halo2_fresh = true;
+    } else {
+        CSIM_HIP(launch_sweep2(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, s->cfg, kind2, s->bc_value, 0,
+                               s->s_comp));
+        s->halo2_fresh = false;
+    }
+    rc = prof_end(s);
+    if (rc) return rc;
+    std::swap(s->cur, s->nxt);
+    s->halo_fresh = false;
+    return CSIM_OK;
+}
+
 int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy, int nsteps) {
     CSIM_REQUIRE(s, "null stepper");
     CSIM_REQUIRE(nsteps >= 0, "nsteps must be >= 0");
+    // Two steps per HBM pass where possible (width a multiple of 128, tile at least 2 x 2).
+    const bool can2 = s->fuse && sweep2_supported(s->nx, s->cfg) && (!s->multi || (s->nx >= 2 && s->ny >= 2));
     if (s->multi && s->external) {
-        if (nsteps > 1)
-            return fail(CSIM_ERR_STATE, "external halo transport advances one step per call");
+        // the caller carries the faces: one step (depth-1 faces) or one fused pass (depth-2) per call
         if (nsteps == 1 && !s->halo_fresh)
             return fail(CSIM_ERR_STATE, "external halo transport: csim_stepper_halo_unpack first");
+        if (nsteps == 2 && !can2)
+            return fail(CSIM_ERR_STATE, "external halo transport: two-step passes are not available here");
+        if (nsteps > 2) return fail(CSIM_ERR_STATE, "external halo transport advances 1 or 2 steps per call");
     } else if (s->multi && !s->comm) {
         return fail(CSIM_ERR_STATE, "multi-rank stepper needs csim_stepper_comm_init before run");
     }
-    const bool rccl = s->multi && !s->external;
     const Phys p = make_phys(s->dx, s->dy, D, dt, vx, vy);
     const GhostArgs g = ghost_args(s);
-    // Two steps per HBM pass where possible.  The LAST step of a call is always a single-step
-    // pass so that the ghost ring left in the field is exactly the reference's (the ring of
-    // the state before the last step, src/main.cpp:104 + src/diffusion.cpp:18-25).
-    const bool can2 = s->fuse && !s->multi && sweep2_supported(s->nx, s->cfg);
-    int kind2[4];
-    for (int k = 0; k < 4; ++k) kind2[k] = s->phys[k] ? s->bc[k] : 3;
-    constexpr size_t POOL = 2048;
+    if (s->multi && s->external && nsteps == 2) return pass_fused(s, p, false);
+    // The LAST step of a call is always a single-step pass so that the ghost ring left in the
+    // field is exactly the reference's (the ring of the state before the last step,
+    // src/main.cpp:104 + src/diffusion.cpp:18-25).
     int remaining = nsteps;
     while (remaining > 0) {
-        const int t = (can2 && remaining >= 3) ? 2 : 1;
-        if (rccl) {
-            if (!s->halo_fresh) {
-                int rc = refresh_halos(s);  // on s_comp: ordered before the ghost fill
-                if (rc) return rc;
-            } else if (s->overlap) {
-                CSIM_HIP(hipStreamWaitEvent(s->s_comp, s->ev_recv, 0));
-            }
+        int rc;
+        if (can2 && remaining >= 3) {
+            rc = pass_fused(s, p, remaining - 2 >= 3);
+            remaining -= 2;
+        } else {
+            rc = pass_single(s, p, g);
+            remaining -= 1;
         }
-        // exchange_halos (unpack) + apply_boundary, mirrored into the partner buffer
-        CSIM_HIP(launch_ghost_fill(s->cur, s->nxt, s->nx, s->ny, s->pitch, g, s->s_comp));
-        if (rccl && s->overlap) {
-            // edge lines of the NEXT field first, so their exchange overlaps the full sweep
-            CSIM_HIP(launch_edge_pack(s->cur, s->nx, s->ny, s->pitch, p, s->send, s->s_comp));
-            CSIM_HIP(hipEventRecord(s->ev_edge, s->s_comp));
-            CSIM_HIP(hipStreamWaitEvent(s->s_comm, s->ev_edge, 0));
-            int rc = post_exchange(s, s->s_comm);
-            if (rc) return rc;
-            CSIM_HIP(hipEventRecord(s->ev_recv, s->s_comm));
-        }
-        if (s->profile) {
-            if (s->ev_used + 2 > POOL) {
-                int rc = prof_fold(s);
-                if (rc) return rc;
-            }
-            while (s->ev_pool.size() < s->ev_used + 2) {
-                hipEvent_t ev;
-                CSIM_HIP(hipEventCreate(&ev));
-                s->ev_pool.push_back(ev);
-            }
-            if (s->ev_steps.size() < s->ev_pool.size() / 2) s->ev_steps.resize(s->ev_pool.size() / 2);
-            s->ev_steps[s->ev_used / 2] = t;
-            CSIM_HIP(hipEventRecord(s->ev_pool[s->ev_used], s->s_comp));
-        }
-        if (t == 2)
-            CSIM_HIP(launch_sweep2(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, s->cfg, kind2,
-                                   s->bc_value, s->s_comp));
-        else
-            CSIM_HIP(launch_sweep(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, s->cfg, s->s_comp));
-        if (s->profile) {
-            CSIM_HIP(hipEventRecord(s->ev_pool[s->ev_used + 1], s->s_comp));
-            s->ev_used += 2;
-        }
-        std::swap(s->cur, s->nxt);
-        if (s->multi && (s->external || !s->overlap)) s->halo_fresh = false;  // exchange again next step
-        remaining -= t;
+        if (rc) return rc;
     }
     return CSIM_OK;
 }

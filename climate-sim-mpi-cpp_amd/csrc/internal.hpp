@@ -70,8 +70,16 @@ hipError_t launch_sweep(const double* in, double* out, int nx, int ny, int pitch
                         const SweepCfg& cfg, hipStream_t st);
 // two fused time steps per pass; kind[s] = CSIM_BC_* on physical sides, 3 on neighbour sides
 bool sweep2_supported(int nx, const SweepCfg& cfg);
+// part: 0 = every tile, 1 = frame tiles only, 2 = all but the frame tiles
 hipError_t launch_sweep2(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
-                         const SweepCfg& cfg, const int kind[4], double value, hipStream_t st);
+                         const SweepCfg& cfg, const int kind[4], double value, int part,
+                         hipStream_t st);
+// depth-2 faces (8 directions: L R B T BL BR TL TR; nullptr = no neighbour there); sizes
+// 2*ny (L,R), 2*(nx+2) (B,T), 4 (corners)
+hipError_t launch_halo2_pack(const double* f, int nx, int ny, int pitch, double* const send[8],
+                             hipStream_t st);
+hipError_t launch_halo2_unpack(double* f, int nx, int ny, int pitch, double* const recv[8],
+                               hipStream_t st);
 hipError_t launch_diffusion_only(const double* in, double* out, int nx, int ny, int pitch,
                                  const Phys& p, hipStream_t st);
 hipError_t launch_advection_only(const double* in, double* out, int nx, int ny, int pitch,

@@ -10,6 +10,8 @@
 // Arithmetic follows the reference's association order exactly (reference
 // src/diffusion.cpp:9-16, src/advection.cpp:13-33) and this file is compiled with
 // -ffp-contract=off, so every kernel is bit-identical to the reference CPU path.
+#include <algorithm>
+
 #include "internal.hpp"
 
 #pragma clang fp contract(off)
@@ -198,14 +200,35 @@ struct Bc2 {
 template <int DIV, int PF>
 __global__ __launch_bounds__(256) void k_sweep2_dpp(const double* __restrict__ in,
                                                     double* __restrict__ out, int nx, int ny,
-                                                    int pitch, int ry, int nwgx, int swz, Phys p,
-                                                    Bc2 bc) {
+                                                    int pitch, int ry, int nwgx, int nchunks,
+                                                    int part, int swz, Phys p, Bc2 bc) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int lin = xcd_remap(blockIdx.x, gridDim.x, swz);
-    const int wgx = lin % nwgx, chunk = lin / nwgx;
+    // part 0: every tile.  part 1: only the FRAME tiles (first/last chunk, first/last
+    // 128-column strip) — launched first on a multi-rank run so that the depth-2 faces can be
+    // packed and sent while part 2 (all the other tiles) is still computing.
+    int wgx, chunk, side = -1;
+    if (part == 1 && nchunks >= 2) {
+        const int b = blockIdx.x;
+        if (b < 2 * nwgx) {
+            chunk = b < nwgx ? 0 : nchunks - 1;
+            wgx = b < nwgx ? b : b - nwgx;
+        } else {
+            chunk = 1 + ((b - 2 * nwgx) >> 1);
+            side = (b - 2 * nwgx) & 1;
+            wgx = side ? nwgx - 1 : 0;
+        }
+    } else {
+        const int lin = xcd_remap(blockIdx.x, gridDim.x, swz);
+        wgx = lin % nwgx;
+        chunk = lin / nwgx;
+    }
     const int c0 = (wgx * 4 + wave) * WAVE_COLS;
     if (c0 >= nx) return;  // wave-uniform
+    if (side == 0 && c0 != 0) return;
+    if (side == 1 && c0 + WAVE_COLS != nx) return;
+    if (part == 2 && (nchunks < 2 || chunk == 0 || chunk == nchunks - 1 || c0 == 0 || c0 + WAVE_COLS == nx))
+        return;
     const int jb = chunk * ry + 1;
     const int je = min(jb + ry - 1, ny);
     const ptrdiff_t xoff = LPAD + c0 + 2 * lane;
@@ -579,6 +602,66 @@ __global__ __launch_bounds__(256) void k_pack(const double* __restrict__ in, int
     }
 }
 
+// ---- depth-2 faces for the two-steps-per-pass sweep on several ranks -------------------------
+// Directions: 0 left, 1 right, 2 bottom, 3 top, 4 bottom-left, 5 bottom-right, 6 top-left,
+// 7 top-right.  Faces hold the two outermost interior columns (2 x ny), rows (2 x (nx+2),
+// ghost columns included so Periodic ghosts travel with them) or the 2 x 2 corner block.
+struct Halo2Ptrs {
+    double* p[8];
+};
+
+__global__ __launch_bounds__(256) void k_halo2_pack(const double* __restrict__ f, int nx, int ny,
+                                                    int pitch, Halo2Ptrs s) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    auto ld = [&](int i, int j) { return f[static_cast<ptrdiff_t>(j) * pitch + (LPAD - 1) + i]; };
+    if (t < 2 * ny) {
+        const int c = t / ny, j = t % ny + 1;
+        if (s.p[0]) s.p[0][t] = ld(1 + c, j);
+        if (s.p[1]) s.p[1][t] = ld(nx - 1 + c, j);
+    }
+    if (t < 2 * (nx + 2)) {
+        const int r = t / (nx + 2), i = t % (nx + 2);
+        if (s.p[2]) s.p[2][t] = ld(i, 1 + r);
+        if (s.p[3]) s.p[3][t] = ld(i, ny - 1 + r);
+    }
+    if (t < 4) {
+        const int r = t >> 1, c = t & 1;
+        if (s.p[4]) s.p[4][t] = ld(1 + c, 1 + r);
+        if (s.p[5]) s.p[5][t] = ld(nx - 1 + c, 1 + r);
+        if (s.p[6]) s.p[6][t] = ld(1 + c, ny - 1 + r);
+        if (s.p[7]) s.p[7][t] = ld(nx - 1 + c, ny - 1 + r);
+    }
+}
+
+// r.p[d] = face received FROM direction d (the neighbour's face of the opposite direction)
+__global__ __launch_bounds__(256) void k_halo2_unpack(double* __restrict__ f, int nx, int ny, int pitch,
+                                                      Halo2Ptrs r) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    auto st = [&](int i, int j, double v) { f[static_cast<ptrdiff_t>(j) * pitch + (LPAD - 1) + i] = v; };
+    if (t < 2 * ny) {
+        const int c = t / ny, j = t % ny + 1;
+        if (r.p[0]) st(-1 + c, j, r.p[0][t]);
+        if (r.p[1]) st(nx + 1 + c, j, r.p[1][t]);
+    }
+    if (t < 2 * (nx + 2)) {
+        const int q = t / (nx + 2), i = t % (nx + 2);
+        // ghost-column entries of a row face are kept only where that side is a physical edge;
+        // next to a neighbour side the corner block of the diagonal rank supplies them
+        const bool keep = (i >= 1 && i <= nx) || (i == 0 && !r.p[0]) || (i == nx + 1 && !r.p[1]);
+        if (keep) {
+            if (r.p[2]) st(i, -1 + q, r.p[2][t]);
+            if (r.p[3]) st(i, ny + 1 + q, r.p[3][t]);
+        }
+    }
+    if (t < 4) {
+        const int q = t >> 1, c = t & 1;
+        if (r.p[4]) st(-1 + c, -1 + q, r.p[4][t]);
+        if (r.p[5]) st(nx + 1 + c, -1 + q, r.p[5][t]);
+        if (r.p[6]) st(-1 + c, ny + 1 + q, r.p[6][t]);
+        if (r.p[7]) st(nx + 1 + c, ny + 1 + q, r.p[7][t]);
+    }
+}
+
 // gaussian hotspot on the device (reference src/init.cpp:12-33); exp() may differ from glibc
 // in the last ulp, so parity runs upload a host-made field instead.
 __global__ __launch_bounds__(256) void k_gaussian(double* __restrict__ f, int nx, int ny, int pitch,
@@ -705,22 +788,25 @@ static hipError_t sweep_div(const double* in, double* out, int nx, int ny, int p
 
 template <int DIV>
 static hipError_t sweep2_div(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
-                             const SweepCfg& cfg, const Bc2& bc, hipStream_t st) {
+                             const SweepCfg& cfg, const Bc2& bc, int part, hipStream_t st) {
     int ry = cfg.rows_per_chunk > 0 ? cfg.rows_per_chunk : 64;
     if (ry > ny) ry = ny;
     const int nchunks = cdiv(ny, ry);
     const int nwgx = cdiv(cdiv(nx, WAVE_COLS), 4);
-    const dim3 grid(nwgx * nchunks);
+    int nblocks = nwgx * nchunks;
+    if (part == 1 && nchunks >= 2) nblocks = 2 * nwgx + 2 * (nchunks - 2);
+    if (part == 2 && nchunks < 3) return hipSuccess;  // every tile is a frame tile
+    const dim3 grid(nblocks);
     const int pf = cfg.prefetch > 0 ? cfg.prefetch : 2;
     if (pf <= 1)
         hipLaunchKernelGGL((k_sweep2_dpp<DIV, 1>), grid, dim3(256), 0, st, in, out, nx, ny, pitch, ry,
-                           nwgx, cfg.xcd_swizzle, p, bc);
+                           nwgx, nchunks, part, cfg.xcd_swizzle, p, bc);
     else if (pf == 2)
         hipLaunchKernelGGL((k_sweep2_dpp<DIV, 2>), grid, dim3(256), 0, st, in, out, nx, ny, pitch, ry,
-                           nwgx, cfg.xcd_swizzle, p, bc);
+                           nwgx, nchunks, part, cfg.xcd_swizzle, p, bc);
     else
         hipLaunchKernelGGL((k_sweep2_dpp<DIV, 4>), grid, dim3(256), 0, st, in, out, nx, ny, pitch, ry,
-                           nwgx, cfg.xcd_swizzle, p, bc);
+                           nwgx, nchunks, part, cfg.xcd_swizzle, p, bc);
     return hipGetLastError();
 }
 
@@ -729,15 +815,34 @@ bool sweep2_supported(int nx, const SweepCfg& cfg) {
 }
 
 hipError_t launch_sweep2(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
-                         const SweepCfg& cfg, const int kind[4], double value, hipStream_t st) {
+                         const SweepCfg& cfg, const int kind[4], double value, int part,
+                         hipStream_t st) {
     Bc2 bc;
     for (int s = 0; s < 4; ++s) bc.kind[s] = kind[s];
     bc.value = value;
     switch (p.div_mode) {
-        case 0: return sweep2_div<0>(in, out, nx, ny, pitch, p, cfg, bc, st);
-        case 1: return sweep2_div<1>(in, out, nx, ny, pitch, p, cfg, bc, st);
-        default: return sweep2_div<2>(in, out, nx, ny, pitch, p, cfg, bc, st);
+        case 0: return sweep2_div<0>(in, out, nx, ny, pitch, p, cfg, bc, part, st);
+        case 1: return sweep2_div<1>(in, out, nx, ny, pitch, p, cfg, bc, part, st);
+        default: return sweep2_div<2>(in, out, nx, ny, pitch, p, cfg, bc, part, st);
     }
+}
+
+hipError_t launch_halo2_pack(const double* f, int nx, int ny, int pitch, double* const send[8],
+                             hipStream_t st) {
+    Halo2Ptrs s;
+    for (int d = 0; d < 8; ++d) s.p[d] = send[d];
+    const int n = std::max(2 * ny, 2 * (nx + 2));
+    hipLaunchKernelGGL(k_halo2_pack, dim3(cdiv(n, 256)), dim3(256), 0, st, f, nx, ny, pitch, s);
+    return hipGetLastError();
+}
+
+hipError_t launch_halo2_unpack(double* f, int nx, int ny, int pitch, double* const recv[8],
+                               hipStream_t st) {
+    Halo2Ptrs r;
+    for (int d = 0; d < 8; ++d) r.p[d] = recv[d];
+    const int n = std::max(2 * ny, 2 * (nx + 2));
+    hipLaunchKernelGGL(k_halo2_unpack, dim3(cdiv(n, 256)), dim3(256), 0, st, f, nx, ny, pitch, r);
+    return hipGetLastError();
 }
 
 hipError_t launch_sweep(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,

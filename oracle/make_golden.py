@@ -70,6 +70,11 @@ RUN_CASES = [
          dt=0.1, steps=6, bc="nddn", ic="random", seed=12, ranks=[1, 2]),
     dict(name="run_tall_3x140", nx=3, ny=140, dx=1.0, dy=1.0, D=0.2, vx=-0.7, vy=-0.1,
          dt=0.1, steps=6, bc="dnnd", ic="random", seed=13, ranks=[1, 3]),
+    # local widths that are multiples of 128: the two-steps-per-pass kernel runs on every rank
+    dict(name="run_fused_256x48", nx=256, ny=48, dx=1.0, dy=1.0, D=0.05, vx=0.5, vy=-0.25,
+         dt=0.1, steps=11, bc="dnpd", ic="random", seed=14, ranks=[1, 2, 4]),
+    dict(name="run_fused_384x36", nx=384, ny=36, dx=1.0, dy=1.0, D=0.1, vx=-0.3, vy=0.4,
+         dt=0.1, steps=8, bc="npnd", ic="random", seed=15, ranks=[1, 3]),
 ]
 
 

@@ -8,6 +8,8 @@ src/halo.cpp:28-43.  Two engines step the local tile:
   --engine oracle        CPU: oracle/cpu_stepper.c (tests the N>1 host logic without a GPU)
   --engine hip-external  GPU: the HIP stepper with csim_stepper_halo_pack/_unpack
                          (several ranks may share one GPU; RCCL refuses that, gloo does not)
+  --engine hip-external2 GPU: same, but two steps per call with depth-2 faces in 8 directions
+                         (csim_stepper_halo2_pack/_unpack) wherever the fused kernel applies
 Rank 0 gathers the global interior and compares it bit-for-bit with the golden fixture."""
 import argparse
 import json
@@ -36,6 +38,25 @@ def exchange(lines, nbr):
     for k in range(4):
         if nbr[k] >= 0:
             reqs.append(dist.isend(torch.from_numpy(np.ascontiguousarray(lines[k])), dst=nbr[k], tag=k))
+    for r in reqs:
+        r.wait()
+    return [g.numpy() if g is not None else None for g in got]
+
+
+def opposite8(d):
+    return d ^ 1 if d < 4 else 11 - d
+
+
+def exchange8(faces, peers):
+    """depth-2 faces, 8 directions (L R B T BL BR TL TR); None where there is no peer."""
+    reqs, got = [], [None] * 8
+    for d in range(8):
+        if peers[d] >= 0:
+            got[d] = torch.empty(faces[d].shape[0], dtype=torch.float64)
+            reqs.append(dist.irecv(got[d], src=peers[d], tag=opposite8(d)))
+    for d in range(8):
+        if peers[d] >= 0:
+            reqs.append(dist.isend(torch.from_numpy(np.ascontiguousarray(faces[d])), dst=peers[d], tag=d))
     for r in reqs:
         r.wait()
     return [g.numpy() if g is not None else None for g in got]
@@ -91,6 +112,25 @@ def main():
         for _ in range(m["steps"]):
             st.halo_unpack(exchange(st.halo_pack(), nbr))
             st.run(m["D"], dt, m["vx"], m["vy"], 1)
+        local = st.download()
+        st.close()
+    elif args.engine == "hip-external2":
+        # two reference steps per call (one fused HBM pass) with depth-2 faces, then single steps
+        csim.lib()
+        csim.set_device(0)
+        st = csim.Stepper(dec, m["dx"], m["dy"], bc)
+        st.set_option("external_halo", 1)
+        st.upload(u)
+        peers, _ = st.halo2_neighbors()
+        remaining = m["steps"]
+        while remaining >= 3:
+            st.halo2_unpack(exchange8(st.halo2_pack(), peers))
+            st.run(m["D"], dt, m["vx"], m["vy"], 2)
+            remaining -= 2
+        while remaining > 0:
+            st.halo_unpack(exchange(st.halo_pack(), nbr))
+            st.run(m["D"], dt, m["vx"], m["vy"], 1)
+            remaining -= 1
         local = st.download()
         st.close()
     else:

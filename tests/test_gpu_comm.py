@@ -53,8 +53,11 @@ def self_neighbor_decomp(csim, nx, ny, sides):
 @pytest.mark.parametrize("sides,bc", [((1, 1, 1, 1), "dddd"), ((1, 1, 0, 0), "ddnd"),
                                       ((0, 0, 1, 1), "npdd"), ((1, 1, 0, 0), "ddpp")])
 @pytest.mark.parametrize("overlap", [1, 0])
-def test_self_exchange_torus(csim, sides, bc, overlap):
-    nx, ny, steps = 300, 170, 7
+@pytest.mark.parametrize("shape", [(300, 170, 7), (256, 170, 9), (1024, 300, 12), (128, 2, 8)])
+def test_self_exchange_torus(csim, sides, bc, overlap, shape):
+    # widths that are multiples of 128 take the fused two-step passes: depth-2 faces and corner
+    # blocks in 8 directions, frame tiles first, exchange overlapped with the remaining tiles
+    nx, ny, steps = shape
     D, vx, vy, dt = 0.05, 0.5, -0.25, 0.1
     rng = np.random.default_rng(17)
     u0 = np.zeros((ny + 2, nx + 2))
@@ -69,7 +72,13 @@ def test_self_exchange_torus(csim, sides, bc, overlap):
     st.run(D, dt, vx, vy, 3)
     st.run(D, dt, vx, vy, steps - 3)
     got = st.download()
+    # the single-step path must give the very same field
+    st.set_option("fuse", 0)
+    st.upload(u0)
+    st.run(D, dt, vx, vy, steps)
+    got1 = st.download()
     st.close()
+    assert np.array_equal(got[1:-1, 1:-1], got1[1:-1, 1:-1])
     # corners are never exchanged (reference leaves them undefined)
     mask = np.ones(got.shape, bool)
     mask[[0, 0, -1, -1], [0, -1, 0, -1]] = False
