@@ -82,7 +82,8 @@ def main():
     ap.add_argument("--rows-per-chunk", type=int, default=0)
     ap.add_argument("--prefetch", type=int, default=0)
     ap.add_argument("--no-overlap", action="store_true")
-    ap.add_argument("--no-fuse", action="store_true", help="one time step per HBM pass only")
+    ap.add_argument("--fuse", type=int, default=-1,
+                    help="time steps per HBM pass: -1 auto (4 on one GPU, 2 across GPUs), 0 off, 2..4")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -116,7 +117,7 @@ def main():
         st.comm_init(box[0])
     for key, val in (("variant", args.variant), ("rows_per_chunk", args.rows_per_chunk),
                      ("prefetch", args.prefetch), ("overlap", 0 if args.no_overlap else 1),
-                     ("fuse", 0 if args.no_fuse else 1)):
+                     ("fuse", args.fuse)):
         st.set_option(key, val)
     st.init_gaussian(1.0, 0.05, 0.5, 0.5)
     dt = min(PHYS["dt"], csim.safe_dt(1.0, 1.0, PHYS["vx"], PHYS["vy"], PHYS["D"]))
@@ -141,9 +142,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     # dominant kernel = the one that advanced most of the timed steps
-    (ms1, n1), (ms2, n2) = st.kernel_time(1), st.kernel_time(2)
-    steps_per_launch = 2 if 2 * n2 >= n1 else 1
-    kern_ms, launches = (ms2, n2) if steps_per_launch == 2 else (ms1, n1)
+    kinds = {t: st.kernel_time(t) for t in (1, 2, 3, 4)}
+    steps_per_launch = max(kinds, key=lambda t: t * kinds[t][1])
+    kern_ms, launches = kinds[steps_per_launch]
     mn, mx = st.minmax()
     st.close()
     if world > 1:
@@ -196,9 +197,9 @@ def main():
                 "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "kernel": "k_sweep2_dpp (copy+diffusion+advection, 2 time steps per HBM pass)"
-                          if steps_per_launch == 2 else
-                          "k_sweep_dpp (copy+diffusion+advection, 1 time step per HBM pass)",
+                "kernel": {1: "k_sweep_dpp", 2: "k_sweep2_dpp", 3: "k_sweepT_dpp<T=3>",
+                           4: "k_sweepT_dpp<T=4>"}[steps_per_launch] +
+                          f" (fused copy+diffusion+advection, {steps_per_launch} time step(s) per HBM pass)",
                 "kernel_avg_ms": kern_avg_ms,
                 "launches_timed": launches,
                 "time_steps_per_launch": steps_per_launch,

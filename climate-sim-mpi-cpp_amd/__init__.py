@@ -397,8 +397,8 @@ class Stepper:
             return ms.value, n.value
         if steps_per_launch is not None:
             return one(steps_per_launch)
-        (m1, n1), (m2, n2) = one(1), one(2)
-        return m1 + m2, n1 + n2, n1 + 2 * n2
+        parts = [(t,) + one(t) for t in (1, 2, 3, 4)]
+        return (sum(p[1] for p in parts), sum(p[2] for p in parts), sum(p[0] * p[2] for p in parts))
 
     def reset_timers(self):
         _ck(lib().csim_stepper_reset_timers(self._h))

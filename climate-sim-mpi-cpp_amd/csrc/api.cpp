@@ -113,7 +113,7 @@ struct csim_stepper {
     int phys[4]{1, 1, 1, 1};
     double bc_value = 0.0;
     int nx = 0, ny = 0, pitch = 0;
-    double* buf[2]{nullptr, nullptr};  // allocations: (ny + 4) rows, see internal.hpp
+    double* buf[2]{nullptr, nullptr};  // allocations incl. the device-only ghost layers, see internal.hpp
     double* cur = nullptr;             // views (row j = 0) into buf[], ping-pong
     double* nxt = nullptr;
     double* scratch = nullptr;
@@ -133,17 +133,17 @@ struct csim_stepper {
     bool halo2_fresh = false;  // recv2[] holds the neighbours' depth-2 faces of `cur`
     SweepCfg cfg;
     int overlap = 1;
-    int fuse = 1;  // two time steps per HBM pass where the kernel supports it
+    int fuse = -1;  // time steps per HBM pass: -1 auto, 0/1 off, 2..4 depth (multi-rank runs cap at 2)
     int external = 0;  // halos are carried by the caller (csim_stepper_halo_pack/_unpack), not RCCL
     int profile = 0;
     std::vector<hipEvent_t> ev_pool;  // start/stop pairs around sweep launches
     std::vector<int> ev_steps;        // time steps covered by each timed launch
     size_t ev_used = 0;
-    double prof_ms[3]{0.0, 0.0, 0.0};   // indexed by time steps per launch (1 or 2)
-    long prof_launches[3]{0, 0, 0};
-    size_t bytes() const { return sizeof(double) * static_cast<size_t>(ny + 4) * pitch; }
+    double prof_ms[MAX_FUSE + 1]{};     // indexed by time steps per launch (1..MAX_FUSE)
+    long prof_launches[MAX_FUSE + 1]{};
+    size_t bytes() const { return sizeof(double) * static_cast<size_t>(ny + 2 + 2 * GHOST_EXTRA) * pitch; }
     // whole-allocation pointer of a view
-    double* base(double* view) const { return view - pitch; }
+    double* base(double* view) const { return view - static_cast<size_t>(GHOST_EXTRA) * pitch; }
 };
 
 extern "C" {
@@ -230,7 +230,7 @@ int csim_field_create(int nx, int ny, int halo, double dx, double dy, csim_field
     f->pitch = pitch_for(nx);
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&f->alloc), f->bytes());
     if (e == hipSuccess) e = hipMemset(f->alloc, 0, f->bytes());
-    if (e == hipSuccess) f->d = f->alloc + f->pitch;
+    if (e == hipSuccess) f->d = f->alloc + static_cast<size_t>(GHOST_EXTRA) * f->pitch;
     if (e == hipSuccess)
         e = hipMalloc(reinterpret_cast<void**>(&f->scratch), sizeof(double) * 2 * REDUCE_BLOCKS);
     if (e != hipSuccess) {
@@ -430,8 +430,8 @@ int csim_stepper_create(const csim_decomp* dec, double dx, double dy, const int 
     }
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) {
-        s->cur = s->buf[0] + s->pitch;
-        s->nxt = s->buf[1] + s->pitch;
+        s->cur = s->buf[0] + static_cast<size_t>(GHOST_EXTRA) * s->pitch;
+        s->nxt = s->buf[1] + static_cast<size_t>(GHOST_EXTRA) * s->pitch;
     }
     if (e != hipSuccess) {
         csim_stepper_destroy(s);
@@ -753,7 +753,7 @@ static int pass_single(csim_stepper* s, const Phys& p, const GhostArgs& g) {
 // TWO reference steps in one HBM pass.  Several ranks: depth-2 faces (8 directions) are staged
 // in recv2[]; when the next pass is fused too, the frame tiles are computed first, their faces
 // packed and sent on the comm stream, and the exchange overlaps the rest of the sweep.
-static int pass_fused(csim_stepper* s, const Phys& p, bool next_fused) {
+static int pass_fused(csim_stepper* s, const Phys& p, bool next_fused, int T = 2) {
     const bool rccl = s->multi && !s->external;
     int kind2[4];
     for (int k = 0; k < 4; ++k) kind2[k] = s->phys[k] ? s->bc[k] : 3;
@@ -772,9 +772,12 @@ static int pass_fused(csim_stepper* s, const Phys& p, bool next_fused) {
         CSIM_HIP(launch_halo2_unpack(s->cur, s->nx, s->ny, s->pitch, s->recv2, s->s_comp));
     }
     CSIM_HIP(launch_ghost_fill(s->cur, s->nxt, s->nx, s->ny, s->pitch, g, s->s_comp));
-    int rc = prof_begin(s, 2);
+    int rc = prof_begin(s, T);
     if (rc) return rc;
-    if (rccl && s->overlap && next_fused) {
+    if (T > 2) {  // single rank only
+        CSIM_HIP(launch_sweepT(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, s->cfg, kind2, s->bc_value, T,
+                               s->s_comp));
+    } else if (rccl && s->overlap && next_fused) {
         CSIM_HIP(launch_sweep2(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, s->cfg, kind2, s->bc_value, 1,
                                s->s_comp));
         CSIM_HIP(launch_halo2_pack(s->nxt, s->nx, s->ny, s->pitch, s->send2, s->s_comp));
@@ -802,7 +805,10 @@ int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy,
     CSIM_REQUIRE(s, "null stepper");
     CSIM_REQUIRE(nsteps >= 0, "nsteps must be >= 0");
     // Two steps per HBM pass where possible (width a multiple of 128, tile at least 2 x 2).
-    const bool can2 = s->fuse && sweep2_supported(s->nx, s->cfg) && (!s->multi || (s->nx >= 2 && s->ny >= 2));
+    // (multi-rank: at most 2, the depth of the exchanged faces; single rank: up to MAX_FUSE)
+    int depth = s->fuse < 0 ? (s->multi ? 2 : MAX_FUSE) : s->fuse;
+    if (s->multi && depth > 2) depth = 2;
+    const bool can2 = depth >= 2 && sweep2_supported(s->nx, s->cfg) && (!s->multi || (s->nx >= 2 && s->ny >= 2));
     if (s->multi && s->external) {
         // the caller carries the faces: one step (depth-1 faces) or one fused pass (depth-2) per call
         if (nsteps == 1 && !s->halo_fresh)
@@ -823,8 +829,9 @@ int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy,
     while (remaining > 0) {
         int rc;
         if (can2 && remaining >= 3) {
-            rc = pass_fused(s, p, remaining - 2 >= 3);
-            remaining -= 2;
+            const int t = std::min(depth, remaining - 1);
+            rc = pass_fused(s, p, remaining - t >= 3, t);
+            remaining -= t;
         } else {
             rc = pass_single(s, p, g);
             remaining -= 1;
@@ -876,7 +883,8 @@ int csim_stepper_set_option(csim_stepper* s, const char* key, long value) {
         s->external = value != 0;
         s->halo_fresh = false;
     } else if (k == "fuse") {
-        s->fuse = value != 0;
+        CSIM_REQUIRE(value >= -1 && value <= MAX_FUSE, "fuse must be -1 (auto) or 0..4");
+        s->fuse = static_cast<int>(value);
     } else if (k == "profile") {
         s->profile = value != 0;
     } else {
@@ -888,7 +896,7 @@ int csim_stepper_set_option(csim_stepper* s, const char* key, long value) {
 int csim_stepper_kernel_time(csim_stepper* s, int steps_per_launch, double* total_ms,
                              long* launches) {
     CSIM_REQUIRE(s && total_ms && launches, "null argument");
-    CSIM_REQUIRE(steps_per_launch == 1 || steps_per_launch == 2, "steps_per_launch must be 1 or 2");
+    CSIM_REQUIRE(steps_per_launch >= 1 && steps_per_launch <= MAX_FUSE, "steps_per_launch must be 1..4");
     int rc = prof_fold(s);
     if (rc) return rc;
     *total_ms = s->prof_ms[steps_per_launch];
@@ -900,7 +908,7 @@ int csim_stepper_reset_timers(csim_stepper* s) {
     CSIM_REQUIRE(s, "null stepper");
     int rc = prof_fold(s);
     if (rc) return rc;
-    for (int t = 0; t < 3; ++t) {
+    for (int t = 0; t <= MAX_FUSE; ++t) {
         s->prof_ms[t] = 0.0;
         s->prof_launches[t] = 0;
     }

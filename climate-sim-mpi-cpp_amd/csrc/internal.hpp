@@ -8,8 +8,9 @@
 //
 //     | 15 unused | ghost i=0 | interior i=1..nx (128-B aligned) | ghost i=nx+1 | pad ... |
 //
-// `view` points one row into the allocation: rows -1 and ny+2 and columns -1 and nx+2 exist as
-// a second (device-only) ghost layer, which the two-steps-per-pass sweep reads.
+// `view` points GHOST_EXTRA rows into the allocation: rows -3..-1 and ny+2..ny+4 (and the pad
+// columns left of i = 0 / right of i = nx+1) exist as device-only ghost layers, which the
+// multi-step-per-pass sweeps read (as halo data on neighbour sides, as don't-care otherwise).
 //
 // pitch = LPAD + round_up(nx + 1, 128) + 16 doubles; for nx = 16384 that is 16544 doubles =
 // 132352 B, an odd multiple of 256 B, so vertically adjacent rows do not alias onto one HBM
@@ -74,6 +75,11 @@ bool sweep2_supported(int nx, const SweepCfg& cfg);
 hipError_t launch_sweep2(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
                          const SweepCfg& cfg, const int kind[4], double value, int part,
                          hipStream_t st);
+// T = 3 or 4 time steps per pass (single rank only: every side a physical edge)
+hipError_t launch_sweepT(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
+                         const SweepCfg& cfg, const int kind[4], double value, int T, hipStream_t st);
+constexpr int MAX_FUSE = 4;       // deepest temporal blocking
+constexpr int GHOST_EXTRA = 3;    // device-only ghost layers beyond the reference's one (= MAX_FUSE-1)
 // depth-2 faces (8 directions: L R B T BL BR TL TR; nullptr = no neighbour there); sizes
 // 2*ny (L,R), 2*(nx+2) (B,T), 4 (corners)
 hipError_t launch_halo2_pack(const double* f, int nx, int ny, int pitch, double* const send[8],
@@ -121,8 +127,10 @@ struct csim_field {
     int nx = 0, ny = 0, halo = 1;
     double dx = 1.0, dy = 1.0;
     int pitch = 0;
-    double* alloc = nullptr;    // (ny + 4) * pitch doubles
-    double* d = nullptr;        // view: alloc + pitch, i.e. row j = 0 of the reference layout
+    double* alloc = nullptr;    // (ny + 2 + 2 * GHOST_EXTRA) * pitch doubles
+    double* d = nullptr;        // view: alloc + GHOST_EXTRA * pitch, i.e. row j = 0 of the reference layout
     double* scratch = nullptr;  // reduction partials
-    size_t bytes() const { return sizeof(double) * static_cast<size_t>(ny + 4) * pitch; }
+    size_t bytes() const {
+        return sizeof(double) * static_cast<size_t>(ny + 2 + 2 * csim::GHOST_EXTRA) * pitch;
+    }
 };

@@ -42,11 +42,25 @@ __device__ __forceinline__ double diffuse_term(double c, double W, double E, dou
     return c + p.kdiff * lap;
 }
 
-template <int DIV>
+// SX / SY: upwind direction known at compile time (1: v >= 0, 0: v < 0, -1: decided at run
+// time).  The compute-bound multi-step kernels are instantiated per sign so that neither both
+// differences nor a per-lane select are evaluated.
+template <int DIV, int SX = -1, int SY = -1>
 __device__ __forceinline__ double advect_term(double c, double W, double E, double S, double N,
                                               const Phys& p) {
-    double gx = (p.vx >= 0.0) ? (c - W) : (E - c);
-    double gy = (p.vy >= 0.0) ? (c - S) : (N - c);
+    double gx, gy;
+    if (SX == 1)
+        gx = c - W;
+    else if (SX == 0)
+        gx = E - c;
+    else
+        gx = (p.vx >= 0.0) ? (c - W) : (E - c);
+    if (SY == 1)
+        gy = c - S;
+    else if (SY == 0)
+        gy = N - c;
+    else
+        gy = (p.vy >= 0.0) ? (c - S) : (N - c);
     if (DIV == 1) {
         gx = gx * p.rdx;
         gy = gy * p.rdy;
@@ -58,11 +72,11 @@ __device__ __forceinline__ double advect_term(double c, double W, double E, doub
     return p.mdt * adv;
 }
 
-template <int DIV>
+template <int DIV, int SX = -1, int SY = -1>
 __device__ __forceinline__ double cell(double c, double W, double E, double S, double N,
                                        const Phys& p) {
     const double o = diffuse_term<DIV>(c, W, E, S, N, p);
-    return o + advect_term<DIV>(c, W, E, S, N, p);
+    return o + advect_term<DIV, SX, SY>(c, W, E, S, N, p);
 }
 
 // ---- cross-lane neighbour moves (DPP, no LDS traffic) ---------------------------------------
@@ -339,6 +353,161 @@ __global__ __launch_bounds__(256) void k_sweep2_dpp(const double* __restrict__ i
             }
         }
     }
+}
+
+// -------------------------------------------------------------------------------------------
+// T time steps per HBM pass (T = 3, 4): the general form of k_sweep2_dpp for a single rank.
+// A wavefront keeps T time levels in registers while it marches: level 0 rows are loaded, level
+// l row (r - l + 1) is produced from level l-1 rows in iteration r, level T is stored.  Level l
+// is needed T - l columns beyond the 128-column strip on each side; those "extras" live in ONE
+// more register per lane, spread over the lanes (lane k <-> column c0-1-k, lane 63-k <-> column
+// c0+128+k), so a whole level of extras costs a single wave-wide cell update:
+//     W(extra) = from_next_lane(X, edge = own .y on lane 63),  E(extra) = from_prev_lane(X, edge
+//     = own .x on lane 0)   — the same expression serves both sides of the strip.
+// Ghost rows / ghost columns of the intermediate levels follow the boundary rule exactly like
+// k_sweep2_dpp (Dirichlet value, Neumann = adjacent interior of the same level, Periodic = the
+// stored ghost).  Cells outside the ghost ring are computed as garbage and never consumed.
+// HBM traffic per cell and pass: 8 B read (+2T/ry halo rows) + 8 B written, for T steps.
+// -------------------------------------------------------------------------------------------
+struct Row3 {
+    double2 m;  // the lane's two strip columns
+    double x;   // the lane's extra column (meaningful on the outer lanes only)
+};
+
+// Register-resident pipeline of T time levels.  To keep every register index static (no
+// rotation moves) the march is unrolled 6-fold: level 0 uses a 6-slot ring (3 rows in use + 3
+// more in flight from HBM), levels 1..T-1 use 3-slot rings, and in iteration k every level
+// writes slot k mod 3 (level 0: the row that arrives sits in slot (k+2) mod 6).
+// EDGE = false is the branch-free body for wavefronts whose strip and (extended) chunk touch no
+// physical edge — the vast majority; EDGE = true adds the boundary rules.
+template <int DIV, int T, bool EDGE, int SX, int SY>
+__device__ __forceinline__ void sweepT_march(const double* __restrict__ in, double* __restrict__ out,
+                                             int ny, int pitch, int jb, int je, int c0, int lane,
+                                             int kl, int kr, const Phys& p, const Bc2& bc) {
+    const ptrdiff_t xoff = LPAD + c0 + 2 * lane;
+    const bool lane0 = lane == 0, lane63 = lane == 63;
+    const bool xlane = lane < T || lane > 63 - T;
+    const ptrdiff_t eoff = lane < 32 ? LPAD + c0 - 1 - lane : LPAD + c0 + WAVE_COLS + (63 - lane);
+    const int kb = bc.kind[CSIM_BOTTOM], kt = bc.kind[CSIM_TOP];
+    const int kx = lane0 ? kl : (lane63 ? kr : 3);
+
+    auto load = [&](int j) {
+        Row3 r;
+        const double* row = in + static_cast<ptrdiff_t>(j) * pitch;
+        r.m = *reinterpret_cast<const double2*>(row + xoff);
+        r.x = 0.0;
+        if (xlane) r.x = row[eoff];
+        return r;
+    };
+
+    const int r_first = jb - (T - 1);
+    const int niter = (je - jb + 1) + 2 * (T - 1);
+    const int last_row = r_first + niter;  // newest level-0 row ever needed (= r_last + 1)
+    Row3 L0[6];
+    Row3 L[T][3];  // L[l] used for l = 1 .. T-1
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        L0[q].m = make_double2(0.0, 0.0);
+        L0[q].x = 0.0;
+        const int row = r_first - 1 + q;
+        if (row <= last_row) L0[q] = load(row);
+    }
+#pragma unroll
+    for (int l = 0; l < T; ++l)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            L[l][q].m = make_double2(0.0, 0.0);
+            L[l][q].x = 0.0;
+        }
+
+    for (int k0 = 0; k0 < niter; k0 += 6) {
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int k = k0 + u;
+            if (k < niter) {  // wave-uniform
+                const int r = r_first + k;  // row of level 1 produced in this iteration
+#pragma unroll
+                for (int l = 1; l <= T; ++l) {
+                    const int rho = r - l + 1;
+                    // rows rho-1, rho, rho+1 of level l-1
+                    const Row3 s = (l == 1) ? L0[u % 6] : L[l - 1][(u + 1) % 3];
+                    const Row3 c = (l == 1) ? L0[(u + 1) % 6] : L[l - 1][(u + 2) % 3];
+                    const Row3 n = (l == 1) ? L0[(u + 2) % 6] : L[l - 1][u % 3];
+                    Row3 o;
+                    bool ghost_row = false;
+                    if (EDGE && l < T) {
+                        const bool gb = rho == 0, gt = rho == ny + 1;
+                        ghost_row = gb || gt;
+                        if (ghost_row) {  // boundary rule instead of the stencil
+                            const int kk = gb ? kb : kt;
+                            if (kk == CSIM_BC_DIRICHLET) {
+                                o.m = make_double2(bc.value, bc.value);
+                                o.x = bc.value;
+                            } else if (kk == CSIM_BC_PERIODIC) {
+                                o = c;
+                            } else if (gt) {  // Neumann top: row ny of this level (made last iteration)
+                                o = L[l][(u + 2) % 3];
+                            } else {  // Neumann bottom: patched when row 1 of this level exists
+                                o.m = make_double2(0.0, 0.0);
+                                o.x = 0.0;
+                            }
+                        }
+                    }
+                    if (!ghost_row) {
+                        const double Wx = from_prev_lane(c.m.y, c.x);
+                        const double Ey = from_next_lane(c.m.x, c.x);
+                        o.m.x = cell<DIV, SX, SY>(c.m.x, Wx, c.m.y, s.m.x, n.m.x, p);
+                        o.m.y = cell<DIV, SX, SY>(c.m.y, c.m.x, Ey, s.m.y, n.m.y, p);
+                        o.x = 0.0;
+                        if (l < T) {
+                            const double xw = from_next_lane(c.x, c.m.y);
+                            const double xe = from_prev_lane(c.x, c.m.x);
+                            o.x = cell<DIV, SX, SY>(c.x, xw, xe, s.x, n.x, p);
+                            if (EDGE) {  // ghost column of this level on a physical edge
+                                o.x = kx == 3 ? o.x
+                                      : kx == CSIM_BC_DIRICHLET ? bc.value
+                                      : kx == CSIM_BC_NEUMANN ? (lane0 ? o.m.x : o.m.y)
+                                                              : c.x;
+                            }
+                        }
+                    }
+                    if (l < T) {
+                        if (EDGE && rho == 1 && kb == CSIM_BC_NEUMANN) L[l][(u + 2) % 3] = o;  // ghost row 0 := row 1
+                        L[l][u % 3] = o;
+                    } else if (rho >= jb) {
+                        *reinterpret_cast<double2*>(out + static_cast<ptrdiff_t>(rho) * pitch + xoff) = o.m;
+                    }
+                }
+                // level-0 row r-1 is dead now: fetch row r+5 into its slot
+                const int rn = r + 5;
+                if (rn <= last_row) L0[u % 6] = load(rn);
+            }
+        }
+    }
+}
+
+template <int DIV, int T, int SX, int SY>
+__global__ __launch_bounds__(256) void k_sweepT_dpp(const double* __restrict__ in,
+                                                    double* __restrict__ out, int nx, int ny,
+                                                    int pitch, int ry, int nwgx, int swz, Phys p,
+                                                    Bc2 bc) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int lin = xcd_remap(blockIdx.x, gridDim.x, swz);
+    const int wgx = lin % nwgx, chunk = lin / nwgx;
+    const int c0 = (wgx * 4 + wave) * WAVE_COLS;
+    if (c0 >= nx) return;  // wave-uniform
+    const int jb = chunk * ry + 1;
+    const int je = min(jb + ry - 1, ny);
+    const int kl = c0 == 0 ? bc.kind[CSIM_LEFT] : 3;
+    const int kr = c0 + WAVE_COLS == nx ? bc.kind[CSIM_RIGHT] : 3;
+    // intermediate-level rows reach T-1 rows beyond the chunk: any chunk that close to the
+    // bottom/top edge meets the ghost rows 0 / ny+1 (the rule fires on the row index alone)
+    const bool edge = kl != 3 || kr != 3 || jb - (T - 1) < 1 || je + (T - 1) > ny;
+    if (edge)
+        sweepT_march<DIV, T, true, SX, SY>(in, out, ny, pitch, jb, je, c0, lane, kl, kr, p, bc);
+    else
+        sweepT_march<DIV, T, false, SX, SY>(in, out, ny, pitch, jb, je, c0, lane, kl, kr, p, bc);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -808,6 +977,45 @@ static hipError_t sweep2_div(const double* in, double* out, int nx, int ny, int 
         hipLaunchKernelGGL((k_sweep2_dpp<DIV, 4>), grid, dim3(256), 0, st, in, out, nx, ny, pitch, ry,
                            nwgx, nchunks, part, cfg.xcd_swizzle, p, bc);
     return hipGetLastError();
+}
+
+template <int DIV, int T>
+static hipError_t sweepT_div(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
+                             const SweepCfg& cfg, const Bc2& bc, hipStream_t st) {
+    int ry = cfg.rows_per_chunk > 0 ? cfg.rows_per_chunk : 128;
+    if (ry > ny) ry = ny;
+    const int nchunks = cdiv(ny, ry);
+    const int nwgx = cdiv(cdiv(nx, WAVE_COLS), 4);
+    const dim3 grid(nwgx * nchunks), block(256);
+    const int sw = cfg.xcd_swizzle;
+    const int sign = (p.vx >= 0.0 ? 2 : 0) + (p.vy >= 0.0 ? 1 : 0);
+    switch (sign) {
+        case 3: hipLaunchKernelGGL((k_sweepT_dpp<DIV, T, 1, 1>), grid, block, 0, st, in, out, nx, ny, pitch, ry, nwgx, sw, p, bc); break;
+        case 2: hipLaunchKernelGGL((k_sweepT_dpp<DIV, T, 1, 0>), grid, block, 0, st, in, out, nx, ny, pitch, ry, nwgx, sw, p, bc); break;
+        case 1: hipLaunchKernelGGL((k_sweepT_dpp<DIV, T, 0, 1>), grid, block, 0, st, in, out, nx, ny, pitch, ry, nwgx, sw, p, bc); break;
+        default: hipLaunchKernelGGL((k_sweepT_dpp<DIV, T, 0, 0>), grid, block, 0, st, in, out, nx, ny, pitch, ry, nwgx, sw, p, bc); break;
+    }
+    return hipGetLastError();
+}
+
+// T = 3 or 4 time steps per pass, single rank (all four sides physical)
+hipError_t launch_sweepT(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
+                         const SweepCfg& cfg, const int kind[4], double value, int T, hipStream_t st) {
+    Bc2 bc;
+    for (int s = 0; s < 4; ++s) bc.kind[s] = kind[s];
+    bc.value = value;
+    if (T == 3) {
+        switch (p.div_mode) {
+            case 0: return sweepT_div<0, 3>(in, out, nx, ny, pitch, p, cfg, bc, st);
+            case 1: return sweepT_div<1, 3>(in, out, nx, ny, pitch, p, cfg, bc, st);
+            default: return sweepT_div<2, 3>(in, out, nx, ny, pitch, p, cfg, bc, st);
+        }
+    }
+    switch (p.div_mode) {
+        case 0: return sweepT_div<0, 4>(in, out, nx, ny, pitch, p, cfg, bc, st);
+        case 1: return sweepT_div<1, 4>(in, out, nx, ny, pitch, p, cfg, bc, st);
+        default: return sweepT_div<2, 4>(in, out, nx, ny, pitch, p, cfg, bc, st);
+    }
 }
 
 bool sweep2_supported(int nx, const SweepCfg& cfg) {

@@ -142,12 +142,12 @@ int csim_stepper_minmax(csim_stepper* s, double out_min_max[2]);
 int csim_stepper_sum(csim_stepper* s, double* out);
 /* tuning / measurement knobs; unknown keys give CSIM_ERR_ARG.
  *   "variant" kernel family (0 auto, 1 dpp, 2 lds, 3 naive), "rows_per_chunk", "prefetch",
- *   "xcd_swizzle" (0/1), "fuse" (0/1: two time steps per HBM pass), "overlap" (0/1: halo
+ *   "xcd_swizzle" (0/1), "fuse" (time steps per HBM pass: -1 auto, 0/1 off, 2..4), "overlap" (0/1: halo
  *   exchange on the second stream), "external_halo" (0/1), "profile" (0/1) */
 int csim_stepper_set_option(csim_stepper* s, const char* key, long value);
 /* with option "profile"=1: HIP-event time (on the compute stream) and count of the sweep
- * launches since the last reset, per kernel kind: steps_per_launch = 2 selects the fused
- * two-steps-per-pass kernel, 1 the single-step kernel */
+ * launches since the last reset, per kernel kind: steps_per_launch = 1 selects the single-step
+ * kernel, 2..4 the kernels that advance that many time steps per HBM pass */
 int csim_stepper_kernel_time(csim_stepper* s, int steps_per_launch, double* total_ms,
                              long* launches);
 int csim_stepper_reset_timers(csim_stepper* s);

@@ -22,7 +22,7 @@ RUN_FILES = sorted(glob.glob(os.path.join(GOLDEN, "run_*.npz")))
 VARIANT_CFGS = [dict(variant=1, prefetch=1), dict(variant=1, prefetch=2), dict(variant=1, prefetch=4),
                 dict(variant=1, prefetch=8, rows_per_chunk=7), dict(variant=1, rows_per_chunk=1),
                 dict(variant=1, xcd_swizzle=0), dict(variant=2), dict(variant=2, rows_per_chunk=5),
-                dict(variant=3), dict(fuse=0)]
+                dict(variant=3), dict(fuse=0), dict(fuse=2), dict(fuse=3), dict(fuse=4)]
 
 
 @pytest.fixture(scope="module")
@@ -206,8 +206,11 @@ def test_seeded_random_vs_oracle_bit_exact(csim, case):
     want = u0.copy()
     ora.run_single(want, dx, dy, D, vx, vy, dt, ora.bc_codes(bc), steps)
     for opts in [dict(variant=1), dict(variant=2), dict(variant=1, prefetch=4, rows_per_chunk=37),
-                 dict(fuse=0), dict(fuse=1, rows_per_chunk=1), dict(fuse=1, rows_per_chunk=3, prefetch=1),
-                 dict(fuse=1, rows_per_chunk=64, prefetch=4), dict(fuse=1, xcd_swizzle=0)]:
+                 dict(fuse=0), dict(fuse=2, rows_per_chunk=1), dict(fuse=2, rows_per_chunk=3, prefetch=1),
+                 dict(fuse=2, rows_per_chunk=64, prefetch=4), dict(fuse=2, xcd_swizzle=0),
+                 dict(fuse=3), dict(fuse=3, rows_per_chunk=2, prefetch=4), dict(fuse=3, rows_per_chunk=1),
+                 dict(fuse=4), dict(fuse=4, rows_per_chunk=5, prefetch=4), dict(fuse=4, xcd_swizzle=0),
+                 dict(fuse=4, rows_per_chunk=1)]:
         got = run_gpu(csim, u0, dx, dy, D, vx, vy, dt, csim.bc_codes(bc), steps, opts)
         assert np.array_equal(got, want), (opts, float(np.abs(got - want).max()))
     got = run_gpu(csim, u0, dx, dy, D, vx, vy, dt, csim.bc_codes(bc), steps, None,
@@ -305,17 +308,18 @@ def _window_check(csim, nx, ny, D, vx, vy, dt, bc, steps, opts, nwin, seed):
     return got
 
 
-def test_full_size_config2_4096_diffusion_periodic(csim):
-    got = _window_check(csim, 4096, 4096, 1.0, 0.0, 0.0, 0.1, "pppp", 6, None, 12, 42)
+@pytest.mark.parametrize("fuse", [-1, 2, 3])
+def test_full_size_config2_4096_diffusion_periodic(csim, fuse):
+    got = _window_check(csim, 4096, 4096, 1.0, 0.0, 0.0, 0.1, "pppp", 9, dict(fuse=fuse), 12, 42)
     assert np.isfinite(got).all()
 
 
 def test_full_size_config3_8192_dirichlet(csim):
-    _window_check(csim, 8192, 8192, 0.05, 0.5, 0.25, 0.1, "dddd", 5, None, 12, 43)
+    _window_check(csim, 8192, 8192, 0.05, 0.5, 0.25, 0.1, "dddd", 6, None, 12, 43)
 
 
 def test_full_size_16384_windows(csim):
-    _window_check(csim, 16384, 16384, 0.05, 0.5, 0.25, 0.1, "dnnd", 4, None, 10, 44)
+    _window_check(csim, 16384, 16384, 0.05, 0.5, 0.25, 0.1, "dnnd", 6, None, 10, 44)
 
 
 def test_physics_sanity_like_reference_integration_tests(csim):

@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--ry", type=int, nargs="+", default=[32, 64, 128, 256])
     ap.add_argument("--pf", type=int, nargs="+", default=[1, 2, 4, 8])
     ap.add_argument("--swz", type=int, nargs="+", default=[1])
-    ap.add_argument("--fuse", type=int, nargs="+", default=[0, 1])
+    ap.add_argument("--fuse", type=int, nargs="+", default=[0, 2, 3, 4])
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     csim = load_package()
@@ -47,7 +47,7 @@ def main():
             for ci, cfg in enumerate(cfgs):
                 for k, val in cfg.items():
                     st.set_option(k, val)
-                st.run(0.05, 0.1, 0.5, 0.25, 3)
+                st.run(0.05, 0.1, 0.5, 0.25, 5)
                 st.sync()
                 st.reset_timers()
                 st.run(0.05, 0.1, 0.5, 0.25, args.steps)
