@@ -123,9 +123,9 @@ def lib() -> C.CDLL:
         "csim_stepper_exchange_halos": (i, [vp]),
         "csim_stepper_halo_pack": (i, [vp, C.POINTER(dp)]),
         "csim_stepper_halo_unpack": (i, [vp, C.POINTER(dp)]),
-        "csim_stepper_halo2_neighbors": (i, [vp, ip, ip]),
-        "csim_stepper_halo2_pack": (i, [vp, C.POINTER(dp)]),
-        "csim_stepper_halo2_unpack": (i, [vp, C.POINTER(dp)]),
+        "csim_stepper_faces_neighbors": (i, [vp, i, ip, ip]),
+        "csim_stepper_faces_pack": (i, [vp, i, C.POINTER(dp)]),
+        "csim_stepper_faces_unpack": (i, [vp, i, C.POINTER(dp)]),
         "csim_stepper_run": (i, [vp, d, d, d, d, i]),
         "csim_stepper_sync": (i, [vp]),
         "csim_stepper_minmax": (i, [vp, dp]),
@@ -327,23 +327,23 @@ class Stepper:
         _ck(lib().csim_stepper_download_interior(self._h, _dp(out)))
         return out
 
-    def halo2_neighbors(self):
+    def faces_neighbors(self, depth):
         peers, lens = (C.c_int * 8)(), (C.c_int * 8)()
-        _ck(lib().csim_stepper_halo2_neighbors(self._h, peers, lens))
+        _ck(lib().csim_stepper_faces_neighbors(self._h, depth, peers, lens))
         return list(peers), list(lens)
 
-    def halo2_pack(self):
-        """depth-2 faces of the current field per direction (None where there is no peer)."""
-        peers, lens = self.halo2_neighbors()
+    def faces_pack(self, depth):
+        """faces of the current field of the given depth per direction (None where no peer)."""
+        peers, lens = self.faces_neighbors(depth)
         bufs = [np.empty(lens[d]) if peers[d] >= 0 else None for d in range(8)]
         arr = (C.POINTER(C.c_double) * 8)(*[_dp(b) if b is not None else None for b in bufs])
-        _ck(lib().csim_stepper_halo2_pack(self._h, arr))
+        _ck(lib().csim_stepper_faces_pack(self._h, depth, arr))
         return bufs
 
-    def halo2_unpack(self, faces):
+    def faces_unpack(self, depth, faces):
         keep = [np.ascontiguousarray(b, dtype=np.float64) if b is not None else None for b in faces]
         arr = (C.POINTER(C.c_double) * 8)(*[_dp(b) if b is not None else None for b in keep])
-        _ck(lib().csim_stepper_halo2_unpack(self._h, arr))
+        _ck(lib().csim_stepper_faces_unpack(self._h, depth, arr))
 
     def init_gaussian(self, A=1.0, sigma_frac=0.05, xc_frac=0.5, yc_frac=0.5):
         _ck(lib().csim_stepper_init_gaussian(self._h, A, sigma_frac, xc_frac, yc_frac))

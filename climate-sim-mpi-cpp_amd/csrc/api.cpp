@@ -126,11 +126,17 @@ struct csim_stepper {
     bool halo_fresh = false;  // recv[] holds the neighbours' edge lines of `cur`
     // depth-2 faces for two-steps-per-pass on several ranks; directions L R B T BL BR TL TR
     int nbr8[8]{-1, -1, -1, -1, -1, -1, -1, -1};
-    size_t len2[8]{0, 0, 0, 0, 0, 0, 0, 0};
+    size_t cap2[8]{0, 0, 0, 0, 0, 0, 0, 0};  // staging capacity (faces of depth MAX_FUSE)
+    // doubles in the face of direction d at depth H
+    size_t face_len(int d, int H) const {
+        return d < 2 ? static_cast<size_t>(H) * (ny + 2) : d < 4 ? static_cast<size_t>(H) * (nx + 2)
+                                                          : static_cast<size_t>(H) * H;
+    }
     double* send2[8]{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double* recv2[8]{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_edge2 = nullptr, ev_recv2 = nullptr;
-    bool halo2_fresh = false;  // recv2[] holds the neighbours' depth-2 faces of `cur`
+    int fuse_cap = 1;     // deepest pass every rank of the decomposition can run (same on all ranks)
+    int faces_depth = 0;  // recv2[] holds the neighbours' faces of `cur` of this depth (0 = none)
     SweepCfg cfg;
     int overlap = 1;
     int fuse = -1;  // time steps per HBM pass: -1 auto, 0/1 off, 2..4 depth (multi-rank runs cap at 2)
@@ -403,6 +409,17 @@ int csim_stepper_create(const csim_decomp* dec, double dx, double dy, const int 
             ok(hipMalloc(reinterpret_cast<void**>(&s->recv[k]), n)) &&
             ok(hipMemset(s->send[k], 0, n)) && ok(hipMemset(s->recv[k], 0, n));
     }
+    // The fused-pass depth must be decided identically on every rank (the face exchange is
+    // collective in effect): all tile widths multiples of 128, depth <= the smallest tile.
+    {
+        const int px = dec->dims[0] > 0 ? dec->dims[0] : 1, py = dec->dims[1] > 0 ? dec->dims[1] : 1;
+        const int gx = dec->nx_global > 0 ? dec->nx_global : s->nx, gy = dec->ny_global > 0 ? dec->ny_global : s->ny;
+        const int bx = gx / px, rx = gx % px, by = gy / py;
+        const bool widths_ok = s->multi ? (bx > 0 && bx % WAVE_COLS == 0 && (bx + rx) % WAVE_COLS == 0)
+                                        : (s->nx % WAVE_COLS == 0);
+        const int min_tile = s->multi ? std::min(bx, by) : MAX_FUSE;
+        s->fuse_cap = widths_ok ? std::max(1, std::min(MAX_FUSE, min_tile)) : 1;
+    }
     // diagonal peers (only where both adjacent sides have neighbours)
     for (int k = 0; k < 4; ++k) s->nbr8[k] = dec->nbr[k];
     {
@@ -418,8 +435,8 @@ int csim_stepper_create(const csim_decomp* dec, double dx, double dy, const int 
     }
     for (int d = 0; d < 8 && e == hipSuccess; ++d) {
         if (s->nbr8[d] < 0) continue;
-        s->len2[d] = d < 2 ? 2 * static_cast<size_t>(s->ny) : d < 4 ? 2 * static_cast<size_t>(s->nx + 2) : 4;
-        const size_t n = sizeof(double) * s->len2[d];
+        s->cap2[d] = s->face_len(d, MAX_FUSE);
+        const size_t n = sizeof(double) * s->cap2[d];
         ok(hipMalloc(reinterpret_cast<void**>(&s->send2[d]), n)) &&
             ok(hipMalloc(reinterpret_cast<void**>(&s->recv2[d]), n)) &&
             ok(hipMemset(s->send2[d], 0, n)) && ok(hipMemset(s->recv2[d], 0, n));
@@ -500,7 +517,7 @@ int csim_stepper_upload(csim_stepper* s, const double* host) {
                             s->s_comp));
     CSIM_HIP(hipStreamSynchronize(s->s_comp));
     s->halo_fresh = false;
-    s->halo2_fresh = false;
+    s->faces_depth = 0;
     return CSIM_OK;
 }
 
@@ -528,7 +545,7 @@ int csim_stepper_init_gaussian(csim_stepper* s, double A, double sigma_frac, dou
                             s->s_comp));
     CSIM_HIP(hipStreamSynchronize(s->s_comp));
     s->halo_fresh = false;
-    s->halo2_fresh = false;
+    s->faces_depth = 0;
     return CSIM_OK;
 }
 
@@ -558,17 +575,17 @@ static int post_exchange(csim_stepper* s, hipStream_t st) {
 // (diagonal ranks are direct xGMI peers too).  Sends go out in direction order, receives are
 // posted in opposite-direction order, so per-peer message order matches even when one peer sits
 // in several directions (a 2-wide process grid, or the self-linked test torus).
-static int post_exchange2(csim_stepper* s, hipStream_t st) {
+static int post_exchange2(csim_stepper* s, int H, hipStream_t st) {
     if (!s->comm) return fail(CSIM_ERR_STATE, "halo exchange needs csim_stepper_comm_init first");
     static const int recv_order[8] = {1, 0, 3, 2, 7, 6, 5, 4};
     CSIM_NCCL(ncclGroupStart());
     for (int d = 0; d < 8; ++d)
         if (s->nbr8[d] >= 0)
-            CSIM_NCCL(ncclSend(s->send2[d], s->len2[d], ncclDouble, s->nbr8[d], s->comm, st));
+            CSIM_NCCL(ncclSend(s->send2[d], s->face_len(d, H), ncclDouble, s->nbr8[d], s->comm, st));
     for (int q = 0; q < 8; ++q) {
         const int d = recv_order[q];
         if (s->nbr8[d] >= 0)
-            CSIM_NCCL(ncclRecv(s->recv2[d], s->len2[d], ncclDouble, s->nbr8[d], s->comm, st));
+            CSIM_NCCL(ncclRecv(s->recv2[d], s->face_len(d, H), ncclDouble, s->nbr8[d], s->comm, st));
     }
     CSIM_NCCL(ncclGroupEnd());
     return CSIM_OK;
@@ -626,41 +643,48 @@ int csim_stepper_halo_unpack(csim_stepper* s, const double* const host_recv[4]) 
     return CSIM_OK;
 }
 
-// depth-2 flavour of the external transport, for csim_stepper_run(.., 2) in external mode
-int csim_stepper_halo2_neighbors(const csim_stepper* s, int peers[8], int lengths[8]) {
+// deep-face flavour of the external transport, for csim_stepper_run(.., depth) in external mode
+static bool depth_ok(const csim_stepper* s, int depth) {
+    return depth >= 2 && depth <= MAX_FUSE && depth <= s->nx && depth <= s->ny;
+}
+
+int csim_stepper_faces_neighbors(const csim_stepper* s, int depth, int peers[8], int lengths[8]) {
     CSIM_REQUIRE(s && peers && lengths, "null argument");
+    CSIM_REQUIRE(depth_ok(s, depth), "face depth must be 2..4 and fit the tile");
     for (int d = 0; d < 8; ++d) {
         peers[d] = s->nbr8[d];
-        lengths[d] = static_cast<int>(s->len2[d]);
+        lengths[d] = s->nbr8[d] >= 0 ? static_cast<int>(s->face_len(d, depth)) : 0;
     }
     return CSIM_OK;
 }
 
-int csim_stepper_halo2_pack(csim_stepper* s, double* const host_send[8]) {
+int csim_stepper_faces_pack(csim_stepper* s, int depth, double* const host_send[8]) {
     CSIM_REQUIRE(s && host_send, "null argument");
+    CSIM_REQUIRE(depth_ok(s, depth), "face depth must be 2..4 and fit the tile");
     if (!s->multi) return CSIM_OK;
-    CSIM_HIP(launch_halo2_pack(s->cur, s->nx, s->ny, s->pitch, s->send2, s->s_comp));
+    CSIM_HIP(launch_halo2_pack(s->cur, s->nx, s->ny, s->pitch, depth, s->send2, s->s_comp));
     for (int d = 0; d < 8; ++d) {
         if (s->nbr8[d] < 0) continue;
         CSIM_REQUIRE(host_send[d], "missing host buffer for a neighbour direction");
-        CSIM_HIP(hipMemcpyAsync(host_send[d], s->send2[d], sizeof(double) * s->len2[d],
+        CSIM_HIP(hipMemcpyAsync(host_send[d], s->send2[d], sizeof(double) * s->face_len(d, depth),
                                 hipMemcpyDeviceToHost, s->s_comp));
     }
     CSIM_HIP(hipStreamSynchronize(s->s_comp));
     return CSIM_OK;
 }
 
-int csim_stepper_halo2_unpack(csim_stepper* s, const double* const host_recv[8]) {
+int csim_stepper_faces_unpack(csim_stepper* s, int depth, const double* const host_recv[8]) {
     CSIM_REQUIRE(s && host_recv, "null argument");
+    CSIM_REQUIRE(depth_ok(s, depth), "face depth must be 2..4 and fit the tile");
     if (!s->multi) return CSIM_OK;
     for (int d = 0; d < 8; ++d) {
         if (s->nbr8[d] < 0) continue;
         CSIM_REQUIRE(host_recv[d], "missing host buffer for a neighbour direction");
-        CSIM_HIP(hipMemcpyAsync(s->recv2[d], host_recv[d], sizeof(double) * s->len2[d],
+        CSIM_HIP(hipMemcpyAsync(s->recv2[d], host_recv[d], sizeof(double) * s->face_len(d, depth),
                                 hipMemcpyHostToDevice, s->s_comp));
     }
     CSIM_HIP(hipStreamSynchronize(s->s_comp));
-    s->halo2_fresh = true;
+    s->faces_depth = depth;
     return CSIM_OK;
 }
 
@@ -746,53 +770,57 @@ static int pass_single(csim_stepper* s, const Phys& p, const GhostArgs& g) {
     if (rc) return rc;
     std::swap(s->cur, s->nxt);
     if (s->multi && (s->external || !s->overlap)) s->halo_fresh = false;  // exchange again next step
-    s->halo2_fresh = false;
+    s->faces_depth = 0;
     return CSIM_OK;
 }
 
-// TWO reference steps in one HBM pass.  Several ranks: depth-2 faces (8 directions) are staged
-// in recv2[]; when the next pass is fused too, the frame tiles are computed first, their faces
-// packed and sent on the comm stream, and the exchange overlaps the rest of the sweep.
-static int pass_fused(csim_stepper* s, const Phys& p, bool next_fused, int T = 2) {
+// T = 2..4 reference steps in one HBM pass.  Several ranks: faces of depth T (8 directions) are
+// staged in recv2[]; when the next pass is fused too (with `next_T` steps), the frame tiles are
+// computed first, their depth-next_T faces packed and sent on the comm stream, and the exchange
+// overlaps the rest of the sweep.
+static hipError_t launch_fused(csim_stepper* s, const Phys& p, const int kind[4], int T, int part) {
+    if (T == 2)
+        return launch_sweep2(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, s->cfg, kind, s->bc_value, part,
+                             s->s_comp);
+    return launch_sweepT(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, s->cfg, kind, s->bc_value, T, part,
+                         s->s_comp);
+}
+
+static int pass_fused(csim_stepper* s, const Phys& p, int T, int next_T) {
     const bool rccl = s->multi && !s->external;
-    int kind2[4];
-    for (int k = 0; k < 4; ++k) kind2[k] = s->phys[k] ? s->bc[k] : 3;
+    int kind[4];
+    for (int k = 0; k < 4; ++k) kind[k] = s->phys[k] ? s->bc[k] : 3;
     GhostArgs g = ghost_args(s);
-    for (int k = 0; k < 4; ++k) g.recv[k] = nullptr;  // neighbour sides come from the depth-2 faces
+    for (int k = 0; k < 4; ++k) g.recv[k] = nullptr;  // neighbour sides come from the deep faces
     if (s->multi) {
-        if (!s->halo2_fresh) {
+        if (s->faces_depth != T) {
             if (s->external)
-                return fail(CSIM_ERR_STATE, "external halo transport: csim_stepper_halo2_unpack first");
-            CSIM_HIP(launch_halo2_pack(s->cur, s->nx, s->ny, s->pitch, s->send2, s->s_comp));
-            int rc = post_exchange2(s, s->s_comp);
+                return fail(CSIM_ERR_STATE, "external halo transport: csim_stepper_faces_unpack (same depth) first");
+            CSIM_HIP(launch_halo2_pack(s->cur, s->nx, s->ny, s->pitch, T, s->send2, s->s_comp));
+            int rc = post_exchange2(s, T, s->s_comp);
             if (rc) return rc;
         } else if (rccl && s->overlap) {
             CSIM_HIP(hipStreamWaitEvent(s->s_comp, s->ev_recv2, 0));
         }
-        CSIM_HIP(launch_halo2_unpack(s->cur, s->nx, s->ny, s->pitch, s->recv2, s->s_comp));
+        CSIM_HIP(launch_halo2_unpack(s->cur, s->nx, s->ny, s->pitch, T, s->recv2, s->s_comp));
     }
     CSIM_HIP(launch_ghost_fill(s->cur, s->nxt, s->nx, s->ny, s->pitch, g, s->s_comp));
+    if (s->multi) CSIM_HIP(launch_ghost_extend(s->cur, s->nx, s->ny, s->pitch, T, g, s->s_comp));
     int rc = prof_begin(s, T);
     if (rc) return rc;
-    if (T > 2) {  // single rank only
-        CSIM_HIP(launch_sweepT(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, s->cfg, kind2, s->bc_value, T,
-                               s->s_comp));
-    } else if (rccl && s->overlap && next_fused) {
-        CSIM_HIP(launch_sweep2(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, s->cfg, kind2, s->bc_value, 1,
-                               s->s_comp));
-        CSIM_HIP(launch_halo2_pack(s->nxt, s->nx, s->ny, s->pitch, s->send2, s->s_comp));
+    if (rccl && s->overlap && next_T >= 2) {
+        CSIM_HIP(launch_fused(s, p, kind, T, 1));
+        CSIM_HIP(launch_halo2_pack(s->nxt, s->nx, s->ny, s->pitch, next_T, s->send2, s->s_comp));
         CSIM_HIP(hipEventRecord(s->ev_edge2, s->s_comp));
         CSIM_HIP(hipStreamWaitEvent(s->s_comm, s->ev_edge2, 0));
-        rc = post_exchange2(s, s->s_comm);
+        rc = post_exchange2(s, next_T, s->s_comm);
         if (rc) return rc;
         CSIM_HIP(hipEventRecord(s->ev_recv2, s->s_comm));
-        CSIM_HIP(launch_sweep2(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, s->cfg, kind2, s->bc_value, 2,
-                               s->s_comp));
-        s->halo2_fresh = true;
+        CSIM_HIP(launch_fused(s, p, kind, T, 2));
+        s->faces_depth = next_T;
     } else {
-        CSIM_HIP(launch_sweep2(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, s->cfg, kind2, s->bc_value, 0,
-                               s->s_comp));
-        s->halo2_fresh = false;
+        CSIM_HIP(launch_fused(s, p, kind, T, 0));
+        s->faces_depth = 0;
     }
     rc = prof_end(s);
     if (rc) return rc;
@@ -804,39 +832,38 @@ static int pass_fused(csim_stepper* s, const Phys& p, bool next_fused, int T = 2
 int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy, int nsteps) {
     CSIM_REQUIRE(s, "null stepper");
     CSIM_REQUIRE(nsteps >= 0, "nsteps must be >= 0");
-    // Two steps per HBM pass where possible (width a multiple of 128, tile at least 2 x 2).
-    // (multi-rank: at most 2, the depth of the exchanged faces; single rank: up to MAX_FUSE)
-    int depth = s->fuse < 0 ? (s->multi ? 2 : MAX_FUSE) : s->fuse;
-    if (s->multi && depth > 2) depth = 2;
-    const bool can2 = depth >= 2 && sweep2_supported(s->nx, s->cfg) && (!s->multi || (s->nx >= 2 && s->ny >= 2));
+    // Up to MAX_FUSE steps per HBM pass where possible: width a multiple of 128 and, across
+    // ranks, a tile at least as large as the face depth.
+    int depth = std::min(s->fuse < 0 ? MAX_FUSE : s->fuse, s->fuse_cap);
+    const bool can_fuse = depth >= 2 && sweep2_supported(s->nx, s->cfg);
     if (s->multi && s->external) {
-        // the caller carries the faces: one step (depth-1 faces) or one fused pass (depth-2) per call
+        // the caller carries the faces: one step (depth-1 faces) or one fused pass per call
         if (nsteps == 1 && !s->halo_fresh)
             return fail(CSIM_ERR_STATE, "external halo transport: csim_stepper_halo_unpack first");
-        if (nsteps == 2 && !can2)
-            return fail(CSIM_ERR_STATE, "external halo transport: two-step passes are not available here");
-        if (nsteps > 2) return fail(CSIM_ERR_STATE, "external halo transport advances 1 or 2 steps per call");
+        if (nsteps >= 2 && !(can_fuse && nsteps <= depth))
+            return fail(CSIM_ERR_STATE, "external halo transport: a call advances 1 step or one fused pass");
     } else if (s->multi && !s->comm) {
         return fail(CSIM_ERR_STATE, "multi-rank stepper needs csim_stepper_comm_init before run");
     }
     const Phys p = make_phys(s->dx, s->dy, D, dt, vx, vy);
     const GhostArgs g = ghost_args(s);
-    if (s->multi && s->external && nsteps == 2) return pass_fused(s, p, false);
+    if (s->multi && s->external && nsteps >= 2) return pass_fused(s, p, nsteps, 0);
     // The LAST step of a call is always a single-step pass so that the ghost ring left in the
     // field is exactly the reference's (the ring of the state before the last step,
     // src/main.cpp:104 + src/diffusion.cpp:18-25).
+    auto pass_len = [&](int remaining) { return (can_fuse && remaining >= 3) ? std::min(depth, remaining - 1) : 1; };
     int remaining = nsteps;
     while (remaining > 0) {
+        const int t = pass_len(remaining);
         int rc;
-        if (can2 && remaining >= 3) {
-            const int t = std::min(depth, remaining - 1);
-            rc = pass_fused(s, p, remaining - t >= 3, t);
-            remaining -= t;
+        if (t >= 2) {
+            const int nt = pass_len(remaining - t);
+            rc = pass_fused(s, p, t, nt >= 2 ? nt : 0);
         } else {
             rc = pass_single(s, p, g);
-            remaining -= 1;
         }
         if (rc) return rc;
+        remaining -= t;
     }
     return CSIM_OK;
 }

@@ -75,17 +75,19 @@ bool sweep2_supported(int nx, const SweepCfg& cfg);
 hipError_t launch_sweep2(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
                          const SweepCfg& cfg, const int kind[4], double value, int part,
                          hipStream_t st);
-// T = 3 or 4 time steps per pass (single rank only: every side a physical edge)
+// T = 3 or 4 time steps per pass (same kind[] / part conventions as launch_sweep2)
 hipError_t launch_sweepT(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
-                         const SweepCfg& cfg, const int kind[4], double value, int T, hipStream_t st);
+                         const SweepCfg& cfg, const int kind[4], double value, int T, int part,
+                         hipStream_t st);
 constexpr int MAX_FUSE = 4;       // deepest temporal blocking
 constexpr int GHOST_EXTRA = 3;    // device-only ghost layers beyond the reference's one (= MAX_FUSE-1)
-// depth-2 faces (8 directions: L R B T BL BR TL TR; nullptr = no neighbour there); sizes
-// 2*ny (L,R), 2*(nx+2) (B,T), 4 (corners)
-hipError_t launch_halo2_pack(const double* f, int nx, int ny, int pitch, double* const send[8],
-                             hipStream_t st);
-hipError_t launch_halo2_unpack(double* f, int nx, int ny, int pitch, double* const recv[8],
-                               hipStream_t st);
+// faces of depth H = 2..4 (8 directions: L R B T BL BR TL TR; nullptr = no neighbour there);
+// sizes H*(ny+2) (L,R), H*(nx+2) (B,T), H*H (corners)
+hipError_t launch_halo2_pack(const double* f, int nx, int ny, int pitch, int depth,
+                             double* const send[8], hipStream_t st);
+hipError_t launch_halo2_unpack(double* f, int nx, int ny, int pitch, int depth,
+                               double* const recv[8], hipStream_t st);
+
 hipError_t launch_diffusion_only(const double* in, double* out, int nx, int ny, int pitch,
                                  const Phys& p, hipStream_t st);
 hipError_t launch_advection_only(const double* in, double* out, int nx, int ny, int pitch,
@@ -102,6 +104,10 @@ struct GhostArgs {
 // boundary fill (+ unpack of received halos) written to `a` and, when b != nullptr, to `b` too
 hipError_t launch_ghost_fill(double* a, double* b, int nx, int ny, int pitch, const GhostArgs& g,
                              hipStream_t st);
+// the boundary rule of a physical side continued over the `depth` halo cells of an adjacent
+// neighbour side (needed by fused passes deeper than the plain ghost fill reaches)
+hipError_t launch_ghost_extend(double* f, int nx, int ny, int pitch, int depth, const GhostArgs& g,
+                               hipStream_t st);
 // updated values of the four edge lines of the NEXT field, computed from `in` and written
 // straight into the send staging buffers (nullptr = side not needed)
 hipError_t launch_edge_pack(const double* in, int nx, int ny, int pitch, const Phys& p,

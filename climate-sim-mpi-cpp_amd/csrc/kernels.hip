@@ -388,7 +388,7 @@ __device__ __forceinline__ void sweepT_march(const double* __restrict__ in, doub
     const bool lane0 = lane == 0, lane63 = lane == 63;
     const bool xlane = lane < T || lane > 63 - T;
     const ptrdiff_t eoff = lane < 32 ? LPAD + c0 - 1 - lane : LPAD + c0 + WAVE_COLS + (63 - lane);
-    const int kb = bc.kind[CSIM_BOTTOM], kt = bc.kind[CSIM_TOP];
+    const int kb = bc.kind[CSIM_BOTTOM], kt = bc.kind[CSIM_TOP];  // 3 = neighbour rank: plain stencil
     const int kx = lane0 ? kl : (lane63 ? kr : 3);
 
     auto load = [&](int j) {
@@ -436,7 +436,7 @@ __device__ __forceinline__ void sweepT_march(const double* __restrict__ in, doub
                     Row3 o;
                     bool ghost_row = false;
                     if (EDGE && l < T) {
-                        const bool gb = rho == 0, gt = rho == ny + 1;
+                        const bool gb = rho == 0 && kb != 3, gt = rho == ny + 1 && kt != 3;
                         ghost_row = gb || gt;
                         if (ghost_row) {  // boundary rule instead of the stencil
                             const int kk = gb ? kb : kt;
@@ -489,21 +489,41 @@ __device__ __forceinline__ void sweepT_march(const double* __restrict__ in, doub
 template <int DIV, int T, int SX, int SY>
 __global__ __launch_bounds__(256) void k_sweepT_dpp(const double* __restrict__ in,
                                                     double* __restrict__ out, int nx, int ny,
-                                                    int pitch, int ry, int nwgx, int swz, Phys p,
-                                                    Bc2 bc) {
+                                                    int pitch, int ry, int nwgx, int nchunks,
+                                                    int part, int swz, Phys p, Bc2 bc) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int lin = xcd_remap(blockIdx.x, gridDim.x, swz);
-    const int wgx = lin % nwgx, chunk = lin / nwgx;
+    // part 0: every tile; 1: frame tiles only; 2: all but the frame tiles (see k_sweep2_dpp)
+    int wgx, chunk, side = -1;
+    if (part == 1 && nchunks >= 2) {
+        const int b = blockIdx.x;
+        if (b < 2 * nwgx) {
+            chunk = b < nwgx ? 0 : nchunks - 1;
+            wgx = b < nwgx ? b : b - nwgx;
+        } else {
+            chunk = 1 + ((b - 2 * nwgx) >> 1);
+            side = (b - 2 * nwgx) & 1;
+            wgx = side ? nwgx - 1 : 0;
+        }
+    } else {
+        const int lin = xcd_remap(blockIdx.x, gridDim.x, swz);
+        wgx = lin % nwgx;
+        chunk = lin / nwgx;
+    }
     const int c0 = (wgx * 4 + wave) * WAVE_COLS;
     if (c0 >= nx) return;  // wave-uniform
+    if (side == 0 && c0 != 0) return;
+    if (side == 1 && c0 + WAVE_COLS != nx) return;
+    if (part == 2 && (nchunks < 2 || chunk == 0 || chunk == nchunks - 1 || c0 == 0 || c0 + WAVE_COLS == nx))
+        return;
     const int jb = chunk * ry + 1;
     const int je = min(jb + ry - 1, ny);
     const int kl = c0 == 0 ? bc.kind[CSIM_LEFT] : 3;
     const int kr = c0 + WAVE_COLS == nx ? bc.kind[CSIM_RIGHT] : 3;
-    // intermediate-level rows reach T-1 rows beyond the chunk: any chunk that close to the
-    // bottom/top edge meets the ghost rows 0 / ny+1 (the rule fires on the row index alone)
-    const bool edge = kl != 3 || kr != 3 || jb - (T - 1) < 1 || je + (T - 1) > ny;
+    // intermediate-level rows reach T-1 rows beyond the chunk: any chunk that close to a
+    // PHYSICAL bottom/top edge meets the ghost rows 0 / ny+1 (the rule fires on the row index)
+    const bool edge = kl != 3 || kr != 3 || (bc.kind[CSIM_BOTTOM] != 3 && jb - (T - 1) < 1) ||
+                      (bc.kind[CSIM_TOP] != 3 && je + (T - 1) > ny);
     if (edge)
         sweepT_march<DIV, T, true, SX, SY>(in, out, ny, pitch, jb, je, c0, lane, kl, kr, p, bc);
     else
@@ -779,55 +799,92 @@ struct Halo2Ptrs {
     double* p[8];
 };
 
+// H = face depth (= time steps of the fused pass that will consume the faces, 2..4).
+// Column faces span rows 0..ny+1 and row faces columns 0..nx+1, i.e. they carry the sender's
+// ghost entries along, so that Periodic (never rewritten) ghosts reach the neighbour.
 __global__ __launch_bounds__(256) void k_halo2_pack(const double* __restrict__ f, int nx, int ny,
-                                                    int pitch, Halo2Ptrs s) {
+                                                    int pitch, int H, Halo2Ptrs s) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     auto ld = [&](int i, int j) { return f[static_cast<ptrdiff_t>(j) * pitch + (LPAD - 1) + i]; };
-    if (t < 2 * ny) {
-        const int c = t / ny, j = t % ny + 1;
+    if (t < H * (ny + 2)) {
+        const int c = t / (ny + 2), j = t % (ny + 2);
         if (s.p[0]) s.p[0][t] = ld(1 + c, j);
-        if (s.p[1]) s.p[1][t] = ld(nx - 1 + c, j);
+        if (s.p[1]) s.p[1][t] = ld(nx - H + 1 + c, j);
     }
-    if (t < 2 * (nx + 2)) {
+    if (t < H * (nx + 2)) {
         const int r = t / (nx + 2), i = t % (nx + 2);
         if (s.p[2]) s.p[2][t] = ld(i, 1 + r);
-        if (s.p[3]) s.p[3][t] = ld(i, ny - 1 + r);
+        if (s.p[3]) s.p[3][t] = ld(i, ny - H + 1 + r);
     }
-    if (t < 4) {
-        const int r = t >> 1, c = t & 1;
+    if (t < H * H) {
+        const int r = t / H, c = t % H;
         if (s.p[4]) s.p[4][t] = ld(1 + c, 1 + r);
-        if (s.p[5]) s.p[5][t] = ld(nx - 1 + c, 1 + r);
-        if (s.p[6]) s.p[6][t] = ld(1 + c, ny - 1 + r);
-        if (s.p[7]) s.p[7][t] = ld(nx - 1 + c, ny - 1 + r);
+        if (s.p[5]) s.p[5][t] = ld(nx - H + 1 + c, 1 + r);
+        if (s.p[6]) s.p[6][t] = ld(1 + c, ny - H + 1 + r);
+        if (s.p[7]) s.p[7][t] = ld(nx - H + 1 + c, ny - H + 1 + r);
     }
 }
 
-// r.p[d] = face received FROM direction d (the neighbour's face of the opposite direction)
+// r.p[d] = face received FROM direction d (the neighbour's face of the opposite direction).
+// The ghost entries a face carries are kept only where the crossing side is a physical edge;
+// next to a neighbour side the corner block of the diagonal rank supplies those cells.
 __global__ __launch_bounds__(256) void k_halo2_unpack(double* __restrict__ f, int nx, int ny, int pitch,
-                                                      Halo2Ptrs r) {
+                                                      int H, Halo2Ptrs r) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     auto st = [&](int i, int j, double v) { f[static_cast<ptrdiff_t>(j) * pitch + (LPAD - 1) + i] = v; };
-    if (t < 2 * ny) {
-        const int c = t / ny, j = t % ny + 1;
-        if (r.p[0]) st(-1 + c, j, r.p[0][t]);
-        if (r.p[1]) st(nx + 1 + c, j, r.p[1][t]);
+    if (t < H * (ny + 2)) {
+        const int c = t / (ny + 2), j = t % (ny + 2);
+        const bool keep = (j >= 1 && j <= ny) || (j == 0 && !r.p[2]) || (j == ny + 1 && !r.p[3]);
+        if (keep) {
+            if (r.p[0]) st(1 - H + c, j, r.p[0][t]);
+            if (r.p[1]) st(nx + 1 + c, j, r.p[1][t]);
+        }
     }
-    if (t < 2 * (nx + 2)) {
+    if (t < H * (nx + 2)) {
         const int q = t / (nx + 2), i = t % (nx + 2);
-        // ghost-column entries of a row face are kept only where that side is a physical edge;
-        // next to a neighbour side the corner block of the diagonal rank supplies them
         const bool keep = (i >= 1 && i <= nx) || (i == 0 && !r.p[0]) || (i == nx + 1 && !r.p[1]);
         if (keep) {
-            if (r.p[2]) st(i, -1 + q, r.p[2][t]);
+            if (r.p[2]) st(i, 1 - H + q, r.p[2][t]);
             if (r.p[3]) st(i, ny + 1 + q, r.p[3][t]);
         }
     }
-    if (t < 4) {
-        const int q = t >> 1, c = t & 1;
-        if (r.p[4]) st(-1 + c, -1 + q, r.p[4][t]);
-        if (r.p[5]) st(nx + 1 + c, -1 + q, r.p[5][t]);
-        if (r.p[6]) st(-1 + c, ny + 1 + q, r.p[6][t]);
+    if (t < H * H) {
+        const int q = t / H, c = t % H;
+        if (r.p[4]) st(1 - H + c, 1 - H + q, r.p[4][t]);
+        if (r.p[5]) st(nx + 1 + c, 1 - H + q, r.p[5][t]);
+        if (r.p[6]) st(1 - H + c, ny + 1 + q, r.p[6][t]);
         if (r.p[7]) st(nx + 1 + c, ny + 1 + q, r.p[7][t]);
+    }
+}
+
+// apply_boundary on the HALO part of a physical side: where a Dirichlet/Neumann edge meets a
+// neighbour side, the ghost line continues over the H halo cells that came from that neighbour
+// (globally, they are the neighbour's own ghost cells of the same physical edge).
+struct GhostExt {
+    int bc[4];
+    int phys[4];
+    double value;
+};
+__global__ __launch_bounds__(64) void k_ghost_extend(double* __restrict__ f, int nx, int ny, int pitch,
+                                                     int H, GhostExt g) {
+    const int t = threadIdx.x;  // 8 segments x H cells
+    const int seg = t / H, k = t % H;
+    if (seg >= 8) return;
+    auto at2 = [&](int i, int j) -> double& { return f[static_cast<ptrdiff_t>(j) * pitch + (LPAD - 1) + i]; };
+    // segments 0..3: physical bottom/top row over the left/right halo columns
+    // segments 4..7: physical left/right column over the bottom/top halo rows
+    if (seg < 4) {
+        const int row_side = (seg & 1) ? CSIM_TOP : CSIM_BOTTOM, col_side = (seg & 2) ? CSIM_RIGHT : CSIM_LEFT;
+        if (!g.phys[row_side] || g.phys[col_side] || g.bc[row_side] == CSIM_BC_PERIODIC) return;
+        const int i = col_side == CSIM_LEFT ? -k : nx + 1 + k;
+        const int jg = row_side == CSIM_BOTTOM ? 0 : ny + 1, ja = row_side == CSIM_BOTTOM ? 1 : ny;
+        at2(i, jg) = g.bc[row_side] == CSIM_BC_DIRICHLET ? g.value : at2(i, ja);
+    } else {
+        const int col_side = (seg & 1) ? CSIM_RIGHT : CSIM_LEFT, row_side = (seg & 2) ? CSIM_TOP : CSIM_BOTTOM;
+        if (!g.phys[col_side] || g.phys[row_side] || g.bc[col_side] == CSIM_BC_PERIODIC) return;
+        const int j = row_side == CSIM_BOTTOM ? -k : ny + 1 + k;
+        const int ig = col_side == CSIM_LEFT ? 0 : nx + 1, ia = col_side == CSIM_LEFT ? 1 : nx;
+        at2(ig, j) = g.bc[col_side] == CSIM_BC_DIRICHLET ? g.value : at2(ia, j);
     }
 }
 
@@ -981,40 +1038,44 @@ static hipError_t sweep2_div(const double* in, double* out, int nx, int ny, int 
 
 template <int DIV, int T>
 static hipError_t sweepT_div(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
-                             const SweepCfg& cfg, const Bc2& bc, hipStream_t st) {
-    int ry = cfg.rows_per_chunk > 0 ? cfg.rows_per_chunk : 128;
+                             const SweepCfg& cfg, const Bc2& bc, int part, hipStream_t st) {
+    int ry = cfg.rows_per_chunk > 0 ? cfg.rows_per_chunk : 64;
     if (ry > ny) ry = ny;
     const int nchunks = cdiv(ny, ry);
     const int nwgx = cdiv(cdiv(nx, WAVE_COLS), 4);
-    const dim3 grid(nwgx * nchunks), block(256);
+    int nblocks = nwgx * nchunks;
+    if (part == 1 && nchunks >= 2) nblocks = 2 * nwgx + 2 * (nchunks - 2);
+    if (part == 2 && nchunks < 3) return hipSuccess;  // every tile is a frame tile
+    const dim3 grid(nblocks), block(256);
     const int sw = cfg.xcd_swizzle;
     const int sign = (p.vx >= 0.0 ? 2 : 0) + (p.vy >= 0.0 ? 1 : 0);
     switch (sign) {
-        case 3: hipLaunchKernelGGL((k_sweepT_dpp<DIV, T, 1, 1>), grid, block, 0, st, in, out, nx, ny, pitch, ry, nwgx, sw, p, bc); break;
-        case 2: hipLaunchKernelGGL((k_sweepT_dpp<DIV, T, 1, 0>), grid, block, 0, st, in, out, nx, ny, pitch, ry, nwgx, sw, p, bc); break;
-        case 1: hipLaunchKernelGGL((k_sweepT_dpp<DIV, T, 0, 1>), grid, block, 0, st, in, out, nx, ny, pitch, ry, nwgx, sw, p, bc); break;
-        default: hipLaunchKernelGGL((k_sweepT_dpp<DIV, T, 0, 0>), grid, block, 0, st, in, out, nx, ny, pitch, ry, nwgx, sw, p, bc); break;
+        case 3: hipLaunchKernelGGL((k_sweepT_dpp<DIV, T, 1, 1>), grid, block, 0, st, in, out, nx, ny, pitch, ry, nwgx, nchunks, part, sw, p, bc); break;
+        case 2: hipLaunchKernelGGL((k_sweepT_dpp<DIV, T, 1, 0>), grid, block, 0, st, in, out, nx, ny, pitch, ry, nwgx, nchunks, part, sw, p, bc); break;
+        case 1: hipLaunchKernelGGL((k_sweepT_dpp<DIV, T, 0, 1>), grid, block, 0, st, in, out, nx, ny, pitch, ry, nwgx, nchunks, part, sw, p, bc); break;
+        default: hipLaunchKernelGGL((k_sweepT_dpp<DIV, T, 0, 0>), grid, block, 0, st, in, out, nx, ny, pitch, ry, nwgx, nchunks, part, sw, p, bc); break;
     }
     return hipGetLastError();
 }
 
-// T = 3 or 4 time steps per pass, single rank (all four sides physical)
+// T = 3 or 4 time steps per pass; kind[s] = CSIM_BC_* on physical sides, 3 on neighbour sides
 hipError_t launch_sweepT(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
-                         const SweepCfg& cfg, const int kind[4], double value, int T, hipStream_t st) {
+                         const SweepCfg& cfg, const int kind[4], double value, int T, int part,
+                         hipStream_t st) {
     Bc2 bc;
     for (int s = 0; s < 4; ++s) bc.kind[s] = kind[s];
     bc.value = value;
     if (T == 3) {
         switch (p.div_mode) {
-            case 0: return sweepT_div<0, 3>(in, out, nx, ny, pitch, p, cfg, bc, st);
-            case 1: return sweepT_div<1, 3>(in, out, nx, ny, pitch, p, cfg, bc, st);
-            default: return sweepT_div<2, 3>(in, out, nx, ny, pitch, p, cfg, bc, st);
+            case 0: return sweepT_div<0, 3>(in, out, nx, ny, pitch, p, cfg, bc, part, st);
+            case 1: return sweepT_div<1, 3>(in, out, nx, ny, pitch, p, cfg, bc, part, st);
+            default: return sweepT_div<2, 3>(in, out, nx, ny, pitch, p, cfg, bc, part, st);
         }
     }
     switch (p.div_mode) {
-        case 0: return sweepT_div<0, 4>(in, out, nx, ny, pitch, p, cfg, bc, st);
-        case 1: return sweepT_div<1, 4>(in, out, nx, ny, pitch, p, cfg, bc, st);
-        default: return sweepT_div<2, 4>(in, out, nx, ny, pitch, p, cfg, bc, st);
+        case 0: return sweepT_div<0, 4>(in, out, nx, ny, pitch, p, cfg, bc, part, st);
+        case 1: return sweepT_div<1, 4>(in, out, nx, ny, pitch, p, cfg, bc, part, st);
+        default: return sweepT_div<2, 4>(in, out, nx, ny, pitch, p, cfg, bc, part, st);
     }
 }
 
@@ -1035,21 +1096,21 @@ hipError_t launch_sweep2(const double* in, double* out, int nx, int ny, int pitc
     }
 }
 
-hipError_t launch_halo2_pack(const double* f, int nx, int ny, int pitch, double* const send[8],
-                             hipStream_t st) {
+hipError_t launch_halo2_pack(const double* f, int nx, int ny, int pitch, int depth,
+                             double* const send[8], hipStream_t st) {
     Halo2Ptrs s;
     for (int d = 0; d < 8; ++d) s.p[d] = send[d];
-    const int n = std::max(2 * ny, 2 * (nx + 2));
-    hipLaunchKernelGGL(k_halo2_pack, dim3(cdiv(n, 256)), dim3(256), 0, st, f, nx, ny, pitch, s);
+    const int n = depth * (std::max(ny, nx) + 2);
+    hipLaunchKernelGGL(k_halo2_pack, dim3(cdiv(n, 256)), dim3(256), 0, st, f, nx, ny, pitch, depth, s);
     return hipGetLastError();
 }
 
-hipError_t launch_halo2_unpack(double* f, int nx, int ny, int pitch, double* const recv[8],
-                               hipStream_t st) {
+hipError_t launch_halo2_unpack(double* f, int nx, int ny, int pitch, int depth,
+                               double* const recv[8], hipStream_t st) {
     Halo2Ptrs r;
     for (int d = 0; d < 8; ++d) r.p[d] = recv[d];
-    const int n = std::max(2 * ny, 2 * (nx + 2));
-    hipLaunchKernelGGL(k_halo2_unpack, dim3(cdiv(n, 256)), dim3(256), 0, st, f, nx, ny, pitch, r);
+    const int n = depth * (std::max(ny, nx) + 2);
+    hipLaunchKernelGGL(k_halo2_unpack, dim3(cdiv(n, 256)), dim3(256), 0, st, f, nx, ny, pitch, depth, r);
     return hipGetLastError();
 }
 
@@ -1125,6 +1186,18 @@ hipError_t launch_pack(const double* in, int nx, int ny, int pitch, double* cons
     const int n = nx > ny ? nx : ny;
     hipLaunchKernelGGL(k_pack, dim3(cdiv(n, 256)), dim3(256), 0, st, in, nx, ny, pitch, send[0],
                        send[1], send[2], send[3]);
+    return hipGetLastError();
+}
+
+hipError_t launch_ghost_extend(double* f, int nx, int ny, int pitch, int depth, const GhostArgs& g,
+                               hipStream_t st) {
+    GhostExt e;
+    for (int s = 0; s < 4; ++s) {
+        e.bc[s] = g.bc[s];
+        e.phys[s] = g.phys[s];
+    }
+    e.value = g.value;
+    hipLaunchKernelGGL(k_ghost_extend, dim3(1), dim3(64), 0, st, f, nx, ny, pitch, depth, e);
     return hipGetLastError();
 }
 

@@ -125,14 +125,15 @@ int csim_stepper_init_gaussian(csim_stepper* s, double A, double sigma_frac, dou
  * next csim_stepper_run(.., 1).  One step per run call in this mode. */
 int csim_stepper_halo_pack(csim_stepper* s, double* const host_send[4]);
 int csim_stepper_halo_unpack(csim_stepper* s, const double* const host_recv[4]);
-/* depth-2 flavour for csim_stepper_run(.., 2) (one fused two-step pass) in external mode:
- * directions 0..7 = left, right, bottom, top, bottom-left, bottom-right, top-left, top-right;
- * _neighbors gives the peer rank (or CSIM_NO_NEIGHBOR) and the face length in doubles per
- * direction.  The face packed for direction d must be delivered to peers[d], which unpacks it
- * as coming from the opposite direction (d ^ 1 for sides, 11 - d for corners). */
-int csim_stepper_halo2_neighbors(const csim_stepper* s, int peers[8], int lengths[8]);
-int csim_stepper_halo2_pack(csim_stepper* s, double* const host_send[8]);
-int csim_stepper_halo2_unpack(csim_stepper* s, const double* const host_recv[8]);
+/* deep-face flavour for csim_stepper_run(.., depth) (ONE fused pass of depth = 2..4 steps) in
+ * external mode: directions 0..7 = left, right, bottom, top, bottom-left, bottom-right, top-left,
+ * top-right; _neighbors gives the peer rank (or CSIM_NO_NEIGHBOR) and the face length in doubles
+ * per direction (depth*(ny+2), depth*(nx+2), depth*depth).  The face packed for direction d must be
+ * delivered to peers[d], which unpacks it as coming from the opposite direction (d ^ 1 for
+ * sides, 11 - d for corners). */
+int csim_stepper_faces_neighbors(const csim_stepper* s, int depth, int peers[8], int lengths[8]);
+int csim_stepper_faces_pack(csim_stepper* s, int depth, double* const host_send[8]);
+int csim_stepper_faces_unpack(csim_stepper* s, int depth, const double* const host_recv[8]);
 /* reference src/halo.cpp:6-50  exchange_halos(u, dec, comm) on the current field */
 int csim_stepper_exchange_halos(csim_stepper* s);
 /* nsteps x { exchange_halos; apply_boundary; fused sweep; swap }, enqueued without host syncs */

@@ -8,8 +8,8 @@ src/halo.cpp:28-43.  Two engines step the local tile:
   --engine oracle        CPU: oracle/cpu_stepper.c (tests the N>1 host logic without a GPU)
   --engine hip-external  GPU: the HIP stepper with csim_stepper_halo_pack/_unpack
                          (several ranks may share one GPU; RCCL refuses that, gloo does not)
-  --engine hip-external2 GPU: same, but two steps per call with depth-2 faces in 8 directions
-                         (csim_stepper_halo2_pack/_unpack) wherever the fused kernel applies
+  --engine hip-external{2,3,4}  GPU: same, but 2/3/4 steps per call (one fused pass) with faces
+                         of that depth in 8 directions (csim_stepper_faces_pack/_unpack)
 Rank 0 gathers the global interior and compares it bit-for-bit with the golden fixture."""
 import argparse
 import json
@@ -114,19 +114,21 @@ def main():
             st.run(m["D"], dt, m["vx"], m["vy"], 1)
         local = st.download()
         st.close()
-    elif args.engine == "hip-external2":
-        # two reference steps per call (one fused HBM pass) with depth-2 faces, then single steps
+    elif args.engine.startswith("hip-external") and args.engine[-1] in "234":
+        # `depth` reference steps per call (one fused HBM pass) with deep faces, then single steps
+        depth = int(args.engine[-1])
         csim.lib()
         csim.set_device(0)
         st = csim.Stepper(dec, m["dx"], m["dy"], bc)
         st.set_option("external_halo", 1)
         st.upload(u)
-        peers, _ = st.halo2_neighbors()
         remaining = m["steps"]
         while remaining >= 3:
-            st.halo2_unpack(exchange8(st.halo2_pack(), peers))
-            st.run(m["D"], dt, m["vx"], m["vy"], 2)
-            remaining -= 2
+            t = min(depth, remaining - 1)
+            peers, _ = st.faces_neighbors(t)
+            st.faces_unpack(t, exchange8(st.faces_pack(t), peers))
+            st.run(m["D"], dt, m["vx"], m["vy"], t)
+            remaining -= t
         while remaining > 0:
             st.halo_unpack(exchange(st.halo_pack(), nbr))
             st.run(m["D"], dt, m["vx"], m["vy"], 1)
