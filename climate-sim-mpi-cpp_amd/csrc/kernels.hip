@@ -1039,7 +1039,15 @@ static hipError_t sweep2_div(const double* in, double* out, int nx, int ny, int 
 template <int DIV, int T>
 static hipError_t sweepT_div(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
                              const SweepCfg& cfg, const Bc2& bc, int part, hipStream_t st) {
-    int ry = cfg.rows_per_chunk > 0 ? cfg.rows_per_chunk : 64;
+    // rows per chunk: 64 on big tiles; smaller tiles (strong scaling across GPUs) trade a little
+    // redundant halo work for enough wavefronts to fill the chip (measured on 4096..16384 tiles:
+    // >= 8192 wavefronts per launch is the knee)
+    int ry = cfg.rows_per_chunk;
+    if (ry <= 0) {
+        const long strips = cdiv(nx, WAVE_COLS);
+        ry = 64;
+        while (ry > 16 && strips * cdiv(ny, ry) < 8192) ry >>= 1;
+    }
     if (ry > ny) ry = ny;
     const int nchunks = cdiv(ny, ry);
     const int nwgx = cdiv(cdiv(nx, WAVE_COLS), 4);

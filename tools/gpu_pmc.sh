@@ -1,15 +1,20 @@
 #!/bin/bash
-# HBM traffic of the sweep kernels from PMC counters, one counter per pass (guide: FETCH_SIZE
-# and WRITE_SIZE do not fit one pass; FETCH_SIZE reads 1/2 of wide streaming reads on gfx950)
+# rocprofv3 evidence for the bench command: kernel-trace stats, then HBM traffic of the sweep
+# kernels from PMC counters, one counter per pass (guide: FETCH_SIZE and WRITE_SIZE do not fit
+# one pass; FETCH_SIZE reads 1/2 of wide streaming reads on gfx950)
 set -x
 mkdir -p gpurun_out
 export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp
+timeout -k 10 600 python3 $R/bench.py --steps 100 --warmup 10 > $R/gpurun_out/bench_full.log 2>&1 || exit 1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $R/gpurun_out/prof_stats.log 2>&1 || exit 1
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 12 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/pmc_$c.log 2>&1 || exit 1
+  timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$c -- python3 $R/bench.py --steps 14 --warmup 3 --no-cpu-baseline > $R/gpurun_out/pmc_$c.log 2>&1 || exit 1
 done
-cd $GRAFT_REPO_ROOT
-find gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE -type f | head -20
+cd $R
+tail -1 gpurun_out/bench_full.log
+for f in $(find gpurun_out/prof_stats -name "*kernel_stats.csv"); do head -8 $f; done
 python3 - <<'PY'
 import csv, glob, collections
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -17,7 +22,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         acc = collections.defaultdict(list)
         for row in csv.DictReader(open(f)):
             if row.get("Counter_Name") == c:
-                acc[row["Kernel_Name"][:60]].append(float(row["Counter_Value"]))
+                acc[row["Kernel_Name"][:70]].append(float(row["Counter_Value"]))
         for k, v in acc.items():
-            print(c, k, "n=", len(v), "mean=", sum(v)/len(v), "min=", min(v), "max=", max(v))
+            print(c, k, "n=", len(v), "mean=", sum(v)/len(v))
 PY

@@ -15,6 +15,7 @@ from __graft_entry__ import load_package  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, nargs="+", default=[16384])
+    ap.add_argument("--shape", type=str, nargs="*", default=[], help="NXxNY tiles, e.g. 4096x8192")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--variants", type=int, nargs="+", default=[1, 2, 3])
@@ -28,8 +29,9 @@ def main():
     csim.lib()
     csim.set_device(0)
     results = []
-    for n in args.n:
-        st = csim.Stepper.single(n, n, 1.0, 1.0, csim.bc_codes("dddd"))
+    shapes = [tuple(int(v) for v in sh.split("x")) for sh in args.shape] or [(n, n) for n in args.n]
+    for (n, n_y) in shapes:
+        st = csim.Stepper.single(n, n_y, 1.0, 1.0, csim.bc_codes("dddd"))
         st.init_gaussian()
         st.set_option("profile", 1)
         cfgs = []
@@ -57,9 +59,9 @@ def main():
         for ci, cfg in enumerate(cfgs):
             ts = sorted(best[ci])
             med = ts[len(ts) // 2]
-            gbs = n * n * 16.0 / (med * 1e-3) / 1e9
-            rec = dict(n=n, **cfg, ms_med=med, ms_min=ts[0], gbs_med=gbs,
-                       gbs_best=n * n * 16.0 / (ts[0] * 1e-3) / 1e9)
+            gbs = n * n_y * 16.0 / (med * 1e-3) / 1e9
+            rec = dict(n=n, ny=n_y, **cfg, ms_med=med, ms_min=ts[0], gbs_med=gbs,
+                       mcells=n * n_y / med / 1e3)
             results.append(rec)
             print(json.dumps(rec), flush=True)
         st.close()
