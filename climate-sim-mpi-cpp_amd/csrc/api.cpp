@@ -120,7 +120,8 @@ struct csim_stepper {
     double* send[4]{nullptr, nullptr, nullptr, nullptr};
     double* recv[4]{nullptr, nullptr, nullptr, nullptr};
     hipStream_t s_comp = nullptr, s_comm = nullptr;
-    hipEvent_t ev_edge = nullptr, ev_recv = nullptr;
+    hipStream_t s_frame = nullptr;  // high priority: frame tiles + face packing of a fused multi-rank pass
+    hipEvent_t ev_edge = nullptr, ev_recv = nullptr, ev_ready = nullptr;
     ncclComm_t comm = nullptr;
     bool multi = false;       // has at least one neighbour
     bool halo_fresh = false;  // recv[] holds the neighbours' edge lines of `cur`
@@ -400,6 +401,7 @@ int csim_stepper_create(const csim_decomp* dec, double dx, double dy, const int 
         ok(hipMalloc(reinterpret_cast<void**>(&s->scratch), sizeof(double) * 2 * REDUCE_BLOCKS)) &&
         ok(hipStreamCreateWithFlags(&s->s_comp, hipStreamNonBlocking)) &&
         ok(hipStreamCreateWithFlags(&s->s_comm, hipStreamNonBlocking)) &&
+        ok(hipEventCreateWithFlags(&s->ev_ready, hipEventDisableTiming)) &&
         ok(hipEventCreateWithFlags(&s->ev_edge, hipEventDisableTiming)) &&
         ok(hipEventCreateWithFlags(&s->ev_recv, hipEventDisableTiming));
     for (int k = 0; k < 4 && e == hipSuccess; ++k) {
@@ -442,6 +444,11 @@ int csim_stepper_create(const csim_decomp* dec, double dx, double dy, const int 
             ok(hipMemset(s->send2[d], 0, n)) && ok(hipMemset(s->recv2[d], 0, n));
     }
     if (e == hipSuccess) {
+        int lo = 0, hi = 0;  // numerically lower = higher priority
+        ok(hipDeviceGetStreamPriorityRange(&lo, &hi)) &&
+            ok(hipStreamCreateWithPriority(&s->s_frame, hipStreamNonBlocking, hi));
+    }
+    if (e == hipSuccess) {
         ok(hipEventCreateWithFlags(&s->ev_edge2, hipEventDisableTiming)) &&
             ok(hipEventCreateWithFlags(&s->ev_recv2, hipEventDisableTiming));
     }
@@ -462,6 +469,7 @@ int csim_stepper_destroy(csim_stepper* s) {
     if (!s) return CSIM_OK;
     if (s->s_comp) (void)hipStreamSynchronize(s->s_comp);
     if (s->s_comm) (void)hipStreamSynchronize(s->s_comm);
+    if (s->s_frame) (void)hipStreamSynchronize(s->s_frame);
     if (s->comm) (void)ncclCommDestroy(s->comm);
     for (hipEvent_t ev : s->ev_pool) (void)hipEventDestroy(ev);
     for (int k = 0; k < 4; ++k) {
@@ -478,6 +486,8 @@ int csim_stepper_destroy(csim_stepper* s) {
     if (s->ev_recv) (void)hipEventDestroy(s->ev_recv);
     if (s->s_comp) (void)hipStreamDestroy(s->s_comp);
     if (s->s_comm) (void)hipStreamDestroy(s->s_comm);
+    if (s->s_frame) (void)hipStreamDestroy(s->s_frame);
+    if (s->ev_ready) (void)hipEventDestroy(s->ev_ready);
     if (s->buf[0]) (void)hipFree(s->buf[0]);
     if (s->buf[1]) (void)hipFree(s->buf[1]);
     if (s->scratch) (void)hipFree(s->scratch);
@@ -778,12 +788,11 @@ static int pass_single(csim_stepper* s, const Phys& p, const GhostArgs& g) {
 // staged in recv2[]; when the next pass is fused too (with `next_T` steps), the frame tiles are
 // computed first, their depth-next_T faces packed and sent on the comm stream, and the exchange
 // overlaps the rest of the sweep.
-static hipError_t launch_fused(csim_stepper* s, const Phys& p, const int kind[4], int T, int part) {
+static hipError_t launch_fused(csim_stepper* s, const Phys& p, const int kind[4], int T, int part,
+                               hipStream_t st) {
     if (T == 2)
-        return launch_sweep2(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, s->cfg, kind, s->bc_value, part,
-                             s->s_comp);
-    return launch_sweepT(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, s->cfg, kind, s->bc_value, T, part,
-                         s->s_comp);
+        return launch_sweep2(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, s->cfg, kind, s->bc_value, part, st);
+    return launch_sweepT(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, s->cfg, kind, s->bc_value, T, part, st);
 }
 
 static int pass_fused(csim_stepper* s, const Phys& p, int T, int next_T) {
@@ -809,17 +818,22 @@ static int pass_fused(csim_stepper* s, const Phys& p, int T, int next_T) {
     int rc = prof_begin(s, T);
     if (rc) return rc;
     if (rccl && s->overlap && next_T >= 2) {
-        CSIM_HIP(launch_fused(s, p, kind, T, 1));
-        CSIM_HIP(launch_halo2_pack(s->nxt, s->nx, s->ny, s->pitch, next_T, s->send2, s->s_comp));
-        CSIM_HIP(hipEventRecord(s->ev_edge2, s->s_comp));
+        // frame tiles + face packing on the high-priority stream, concurrently with the other
+        // tiles on the compute stream; the exchange follows on the comm stream
+        CSIM_HIP(hipEventRecord(s->ev_ready, s->s_comp));
+        CSIM_HIP(hipStreamWaitEvent(s->s_frame, s->ev_ready, 0));
+        CSIM_HIP(launch_fused(s, p, kind, T, 1, s->s_frame));
+        CSIM_HIP(launch_halo2_pack(s->nxt, s->nx, s->ny, s->pitch, next_T, s->send2, s->s_frame));
+        CSIM_HIP(hipEventRecord(s->ev_edge2, s->s_frame));
         CSIM_HIP(hipStreamWaitEvent(s->s_comm, s->ev_edge2, 0));
         rc = post_exchange2(s, next_T, s->s_comm);
         if (rc) return rc;
         CSIM_HIP(hipEventRecord(s->ev_recv2, s->s_comm));
-        CSIM_HIP(launch_fused(s, p, kind, T, 2));
+        CSIM_HIP(launch_fused(s, p, kind, T, 2, s->s_comp));
+        CSIM_HIP(hipStreamWaitEvent(s->s_comp, s->ev_edge2, 0));  // the pass ends when both parts have
         s->faces_depth = next_T;
     } else {
-        CSIM_HIP(launch_fused(s, p, kind, T, 0));
+        CSIM_HIP(launch_fused(s, p, kind, T, 0, s->s_comp));
         s->faces_depth = 0;
     }
     rc = prof_end(s);
@@ -872,6 +886,7 @@ int csim_stepper_sync(csim_stepper* s) {
     CSIM_REQUIRE(s, "null stepper");
     CSIM_HIP(hipStreamSynchronize(s->s_comp));
     CSIM_HIP(hipStreamSynchronize(s->s_comm));
+    CSIM_HIP(hipStreamSynchronize(s->s_frame));
     return CSIM_OK;
 }
 
@@ -902,6 +917,8 @@ int csim_stepper_set_option(csim_stepper* s, const char* key, long value) {
     } else if (k == "prefetch") {
         CSIM_REQUIRE(value >= 0 && value <= 8, "prefetch must be 0..8");
         s->cfg.prefetch = static_cast<int>(value);
+    } else if (k == "wide") {
+        s->cfg.wide = value != 0;
     } else if (k == "xcd_swizzle") {
         s->cfg.xcd_swizzle = value != 0;
     } else if (k == "overlap") {

@@ -63,6 +63,7 @@ struct SweepCfg {
     int rows_per_chunk = 0;  // 0 = auto
     int prefetch = 0;        // 0 = auto (rows kept in flight per wavefront)
     int xcd_swizzle = 1;
+    int wide = 0;            // T >= 3 sweeps: 256-column strips per wavefront (needs nx % 256 == 0)
 };
 
 // ---- kernel launchers (kernels.hip) --------------------------------------------------------

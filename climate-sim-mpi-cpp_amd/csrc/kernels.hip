@@ -531,6 +531,185 @@ __global__ __launch_bounds__(256) void k_sweepT_dpp(const double* __restrict__ i
 }
 
 // -------------------------------------------------------------------------------------------
+// Wide flavour of the T-step sweep: one wavefront owns 256 columns as two 128-column halves
+// (lane l holds columns 2l,2l+1 of each half, so both row loads stay 16-byte-per-lane and fully
+// coalesced).  The kernel is VALU-bound at T >= 3, and the per-level cost of the extra columns is
+// one wave-wide cell update whatever the strip width: over 256 columns it is 5 updates per 4
+// useful ones instead of 3 per 2 (-17 % arithmetic).  The seam between the halves is bridged by
+// v_readlane (lane 63 of half A <-> lane 0 of half B).  Needs nx % 256 == 0.
+// -------------------------------------------------------------------------------------------
+constexpr int WIDE_COLS = 256;
+
+struct Row5 {
+    double2 a, b;  // the lane's columns in the two halves of the strip
+    double x;      // the lane's extra column (outer lanes only)
+};
+
+__device__ __forceinline__ double lane_value(double v, int src_lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+template <int DIV, int T, bool EDGE, int SX, int SY>
+__device__ __forceinline__ void sweepTw_march(const double* __restrict__ in, double* __restrict__ out,
+                                              int ny, int pitch, int jb, int je, int c0, int lane,
+                                              int kl, int kr, const Phys& p, const Bc2& bc) {
+    const ptrdiff_t xoffA = LPAD + c0 + 2 * lane;
+    const ptrdiff_t xoffB = xoffA + WAVE_COLS;
+    const bool lane0 = lane == 0, lane63 = lane == 63;
+    const bool xlane = lane < T || lane > 63 - T;
+    const ptrdiff_t eoff = lane < 32 ? LPAD + c0 - 1 - lane : LPAD + c0 + WIDE_COLS + (63 - lane);
+    const int kb = bc.kind[CSIM_BOTTOM], kt = bc.kind[CSIM_TOP];  // 3 = neighbour rank: plain stencil
+    const int kx = lane0 ? kl : (lane63 ? kr : 3);
+
+    auto load = [&](int j) {
+        Row5 r;
+        const double* row = in + static_cast<ptrdiff_t>(j) * pitch;
+        r.a = *reinterpret_cast<const double2*>(row + xoffA);
+        r.b = *reinterpret_cast<const double2*>(row + xoffB);
+        r.x = 0.0;
+        if (xlane) r.x = row[eoff];
+        return r;
+    };
+    auto zero = [] {
+        Row5 r;
+        r.a = make_double2(0.0, 0.0);
+        r.b = make_double2(0.0, 0.0);
+        r.x = 0.0;
+        return r;
+    };
+
+    const int r_first = jb - (T - 1);
+    const int niter = (je - jb + 1) + 2 * (T - 1);
+    const int last_row = r_first + niter;
+    Row5 L0[6];
+    Row5 L[T][3];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        L0[q] = zero();
+        const int row = r_first - 1 + q;
+        if (row <= last_row) L0[q] = load(row);
+    }
+#pragma unroll
+    for (int l = 0; l < T; ++l)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) L[l][q] = zero();
+
+    for (int k0 = 0; k0 < niter; k0 += 6) {
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int k = k0 + u;
+            if (k < niter) {  // wave-uniform
+                const int r = r_first + k;
+#pragma unroll
+                for (int l = 1; l <= T; ++l) {
+                    const int rho = r - l + 1;
+                    const Row5 s = (l == 1) ? L0[u % 6] : L[l - 1][(u + 1) % 3];
+                    const Row5 c = (l == 1) ? L0[(u + 1) % 6] : L[l - 1][(u + 2) % 3];
+                    const Row5 n = (l == 1) ? L0[(u + 2) % 6] : L[l - 1][u % 3];
+                    Row5 o;
+                    bool ghost_row = false;
+                    if (EDGE && l < T) {
+                        const bool gb = rho == 0 && kb != 3, gt = rho == ny + 1 && kt != 3;
+                        ghost_row = gb || gt;
+                        if (ghost_row) {
+                            const int kk = gb ? kb : kt;
+                            if (kk == CSIM_BC_DIRICHLET) {
+                                o.a = make_double2(bc.value, bc.value);
+                                o.b = o.a;
+                                o.x = bc.value;
+                            } else if (kk == CSIM_BC_PERIODIC) {
+                                o = c;
+                            } else if (gt) {
+                                o = L[l][(u + 2) % 3];
+                            } else {
+                                o = zero();
+                            }
+                        }
+                    }
+                    if (!ghost_row) {
+                        const double seamA = lane_value(c.a.y, 63);  // column c0+127
+                        const double seamB = lane_value(c.b.x, 0);   // column c0+128
+                        const double Wax = from_prev_lane(c.a.y, c.x);
+                        const double Eay = from_next_lane(c.a.x, seamB);
+                        const double Wbx = from_prev_lane(c.b.y, seamA);
+                        const double Eby = from_next_lane(c.b.x, c.x);
+                        o.a.x = cell<DIV, SX, SY>(c.a.x, Wax, c.a.y, s.a.x, n.a.x, p);
+                        o.a.y = cell<DIV, SX, SY>(c.a.y, c.a.x, Eay, s.a.y, n.a.y, p);
+                        o.b.x = cell<DIV, SX, SY>(c.b.x, Wbx, c.b.y, s.b.x, n.b.x, p);
+                        o.b.y = cell<DIV, SX, SY>(c.b.y, c.b.x, Eby, s.b.y, n.b.y, p);
+                        o.x = 0.0;
+                        if (l < T) {
+                            const double xw = from_next_lane(c.x, c.b.y);
+                            const double xe = from_prev_lane(c.x, c.a.x);
+                            o.x = cell<DIV, SX, SY>(c.x, xw, xe, s.x, n.x, p);
+                            if (EDGE) {
+                                o.x = kx == 3 ? o.x
+                                      : kx == CSIM_BC_DIRICHLET ? bc.value
+                                      : kx == CSIM_BC_NEUMANN ? (lane0 ? o.a.x : o.b.y)
+                                                              : c.x;
+                            }
+                        }
+                    }
+                    if (l < T) {
+                        if (EDGE && rho == 1 && kb == CSIM_BC_NEUMANN) L[l][(u + 2) % 3] = o;
+                        L[l][u % 3] = o;
+                    } else if (rho >= jb) {
+                        double* dst = out + static_cast<ptrdiff_t>(rho) * pitch;
+                        *reinterpret_cast<double2*>(dst + xoffA) = o.a;
+                        *reinterpret_cast<double2*>(dst + xoffB) = o.b;
+                    }
+                }
+                const int rn = r + 5;
+                if (rn <= last_row) L0[u % 6] = load(rn);
+            }
+        }
+    }
+}
+
+template <int DIV, int T, int SX, int SY>
+__global__ __launch_bounds__(256) void k_sweepTw_dpp(const double* __restrict__ in,
+                                                     double* __restrict__ out, int nx, int ny,
+                                                     int pitch, int ry, int nwgx, int nchunks,
+                                                     int part, int swz, Phys p, Bc2 bc) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    int wgx, chunk, side = -1;
+    if (part == 1 && nchunks >= 2) {
+        const int b = blockIdx.x;
+        if (b < 2 * nwgx) {
+            chunk = b < nwgx ? 0 : nchunks - 1;
+            wgx = b < nwgx ? b : b - nwgx;
+        } else {
+            chunk = 1 + ((b - 2 * nwgx) >> 1);
+            side = (b - 2 * nwgx) & 1;
+            wgx = side ? nwgx - 1 : 0;
+        }
+    } else {
+        const int lin = xcd_remap(blockIdx.x, gridDim.x, swz);
+        wgx = lin % nwgx;
+        chunk = lin / nwgx;
+    }
+    const int c0 = (wgx * 4 + wave) * WIDE_COLS;
+    if (c0 >= nx) return;  // wave-uniform
+    if (side == 0 && c0 != 0) return;
+    if (side == 1 && c0 + WIDE_COLS != nx) return;
+    if (part == 2 && (nchunks < 2 || chunk == 0 || chunk == nchunks - 1 || c0 == 0 || c0 + WIDE_COLS == nx))
+        return;
+    const int jb = chunk * ry + 1;
+    const int je = min(jb + ry - 1, ny);
+    const int kl = c0 == 0 ? bc.kind[CSIM_LEFT] : 3;
+    const int kr = c0 + WIDE_COLS == nx ? bc.kind[CSIM_RIGHT] : 3;
+    const bool edge = kl != 3 || kr != 3 || (bc.kind[CSIM_BOTTOM] != 3 && jb - (T - 1) < 1) ||
+                      (bc.kind[CSIM_TOP] != 3 && je + (T - 1) > ny);
+    if (edge)
+        sweepTw_march<DIV, T, true, SX, SY>(in, out, ny, pitch, jb, je, c0, lane, kl, kr, p, bc);
+    else
+        sweepTw_march<DIV, T, false, SX, SY>(in, out, ny, pitch, jb, je, c0, lane, kl, kr, p, bc);
+}
+
+// -------------------------------------------------------------------------------------------
 // VAR_LDS — LDS-staged marching sweep.  A 256-thread workgroup owns a 512-column strip; every
 // row is loaded once (16 B per lane), staged in a double-buffered LDS row (ds_write_b128) with
 // its two halo columns, and the W/E neighbours are read back from LDS (ds_read_b64); N/S stay
@@ -1039,30 +1218,46 @@ static hipError_t sweep2_div(const double* in, double* out, int nx, int ny, int 
 template <int DIV, int T>
 static hipError_t sweepT_div(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
                              const SweepCfg& cfg, const Bc2& bc, int part, hipStream_t st) {
+    const bool wide = cfg.wide != 0 && nx % WIDE_COLS == 0;
+    const int strip = wide ? WIDE_COLS : WAVE_COLS;
     // rows per chunk: 64 on big tiles; smaller tiles (strong scaling across GPUs) trade a little
     // redundant halo work for enough wavefronts to fill the chip (measured on 4096..16384 tiles:
-    // >= 8192 wavefronts per launch is the knee)
+    // >= 8192 wavefronts per launch is the knee for the 128-column strips)
     int ry = cfg.rows_per_chunk;
     if (ry <= 0) {
-        const long strips = cdiv(nx, WAVE_COLS);
+        const long strips = cdiv(nx, strip);
+        const long want = wide ? 4096 : 8192;
         ry = 64;
-        while (ry > 16 && strips * cdiv(ny, ry) < 8192) ry >>= 1;
+        while (ry > 16 && strips * cdiv(ny, ry) < want) ry >>= 1;
     }
     if (ry > ny) ry = ny;
     const int nchunks = cdiv(ny, ry);
-    const int nwgx = cdiv(cdiv(nx, WAVE_COLS), 4);
+    const int nwgx = cdiv(cdiv(nx, strip), 4);
     int nblocks = nwgx * nchunks;
     if (part == 1 && nchunks >= 2) nblocks = 2 * nwgx + 2 * (nchunks - 2);
     if (part == 2 && nchunks < 3) return hipSuccess;  // every tile is a frame tile
     const dim3 grid(nblocks), block(256);
     const int sw = cfg.xcd_swizzle;
     const int sign = (p.vx >= 0.0 ? 2 : 0) + (p.vy >= 0.0 ? 1 : 0);
-    switch (sign) {
-        case 3: hipLaunchKernelGGL((k_sweepT_dpp<DIV, T, 1, 1>), grid, block, 0, st, in, out, nx, ny, pitch, ry, nwgx, nchunks, part, sw, p, bc); break;
-        case 2: hipLaunchKernelGGL((k_sweepT_dpp<DIV, T, 1, 0>), grid, block, 0, st, in, out, nx, ny, pitch, ry, nwgx, nchunks, part, sw, p, bc); break;
-        case 1: hipLaunchKernelGGL((k_sweepT_dpp<DIV, T, 0, 1>), grid, block, 0, st, in, out, nx, ny, pitch, ry, nwgx, nchunks, part, sw, p, bc); break;
-        default: hipLaunchKernelGGL((k_sweepT_dpp<DIV, T, 0, 0>), grid, block, 0, st, in, out, nx, ny, pitch, ry, nwgx, nchunks, part, sw, p, bc); break;
+#define CSIM_LAUNCH_T(KERNEL, SXV, SYV)                                                               \
+    hipLaunchKernelGGL((KERNEL<DIV, T, SXV, SYV>), grid, block, 0, st, in, out, nx, ny, pitch, ry, nwgx, \
+                       nchunks, part, sw, p, bc)
+    if (wide) {
+        switch (sign) {
+            case 3: CSIM_LAUNCH_T(k_sweepTw_dpp, 1, 1); break;
+            case 2: CSIM_LAUNCH_T(k_sweepTw_dpp, 1, 0); break;
+            case 1: CSIM_LAUNCH_T(k_sweepTw_dpp, 0, 1); break;
+            default: CSIM_LAUNCH_T(k_sweepTw_dpp, 0, 0); break;
+        }
+    } else {
+        switch (sign) {
+            case 3: CSIM_LAUNCH_T(k_sweepT_dpp, 1, 1); break;
+            case 2: CSIM_LAUNCH_T(k_sweepT_dpp, 1, 0); break;
+            case 1: CSIM_LAUNCH_T(k_sweepT_dpp, 0, 1); break;
+            default: CSIM_LAUNCH_T(k_sweepT_dpp, 0, 0); break;
+        }
     }
+#undef CSIM_LAUNCH_T
     return hipGetLastError();
 }
 

@@ -53,8 +53,11 @@ def self_neighbor_decomp(csim, nx, ny, sides):
 @pytest.mark.parametrize("sides,bc", [((1, 1, 1, 1), "dddd"), ((1, 1, 0, 0), "ddnd"),
                                       ((0, 0, 1, 1), "npdd"), ((1, 1, 0, 0), "ddpp")])
 @pytest.mark.parametrize("overlap", [1, 0])
-@pytest.mark.parametrize("shape", [(300, 170, 7), (256, 170, 9), (1024, 300, 12), (128, 2, 8)])
+@pytest.mark.parametrize("shape", [(300, 170, 7), (256, 170, 9), (1024, 300, 12), (128, 2, 8),
+                                   (1024, 300, 12, "wide")])
 def test_self_exchange_torus(csim, sides, bc, overlap, shape):
+    wide = len(shape) == 4
+    shape = shape[:3]
     # widths that are multiples of 128 take the fused two-step passes: depth-2 faces and corner
     # blocks in 8 directions, frame tiles first, exchange overlapped with the remaining tiles
     nx, ny, steps = shape
@@ -68,6 +71,7 @@ def test_self_exchange_torus(csim, sides, bc, overlap, shape):
     st = csim.Stepper(self_neighbor_decomp(csim, nx, ny, sides), 1.0, 1.0, codes)
     st.comm_init(csim.comm_unique_id())
     st.set_option("overlap", overlap)
+    st.set_option("wide", 1 if wide else 0)
     st.upload(u0)
     st.run(D, dt, vx, vy, 3)
     st.run(D, dt, vx, vy, steps - 3)

@@ -76,3 +76,29 @@ def test_driver_mpi_four_ranks_one_gpu(tmp_path):
     rec = records(h, m)
     assert np.array_equal(rec[0], z["u0"]) and np.array_equal(rec[1], z["u_final"])
     assert "dims=2x2" in out
+
+
+def test_driver_ic_from_netcdf_file(tmp_path):
+    """BASELINE config 5's "NetCDF initial-condition load": the reference has no reader (ic.mode=file
+    throws there); ours loads a classic NetCDF (y,x) double variable.  A random field
+    written with the snapshot writer must step exactly like the golden run that started from it."""
+    z, m = golden("run_fused_256x48")
+    raw = tmp_path / "ic.bin"
+    np.ascontiguousarray(z["u0"]).tofile(raw)
+    ic = tmp_path / "ic.nc"
+    subprocess.run([os.path.join(DRV, "csim_hosttool"), "nc-write", str(ic), str(raw), "1",
+                    f"--nx={m['nx']}", f"--ny={m['ny']}"], check=True)
+    m2 = dict(m, sigma_frac=0.05)
+    out, h = run_driver(tmp_path, "climate_sim_hip", m2, m["steps"] + 1, m["steps"],
+                        extra=("--ic.mode=file", f"--ic.path={ic}"))
+    rec = records(h, m)
+    assert np.array_equal(rec[0], z["u0"]) and np.array_equal(rec[1], z["u_final"])
+
+
+def test_driver_rejects_bad_ic(tmp_path):
+    """reference tests/simulation/integration/integration_boundary_error.cpp: a bad IC preset gives
+    a non-zero exit and no output file."""
+    r = subprocess.run([os.path.join(DRV, "climate_sim_hip"), "--nx=32", "--ny=32", "--steps=2",
+                        "--ic.preset=no_such_preset"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode != 0
+    assert not os.path.exists(os.path.join(tmp_path, "outputs", "snapshots.nc"))

@@ -192,6 +192,8 @@ SEEDED = [
     (640, 67, 1.0, 1.0, 0.05, 0.5, -0.25, 0.1, "ndnd", 11),
     (256, 40, 0.5, 0.25, 0.01, 0.3, -0.2, 0.05, "dnnd", 9),     # exact-reciprocal path, fused
     (128, 30, 0.7, 1.3, 0.08, -0.6, 0.9, 0.1, "npdn", 7),       # IEEE-division path, fused
+    (512, 70, 1.0, 1.0, 0.1, -0.3, 0.2, 0.1, "dnpn", 10),       # 2 wide (256-column) strips
+    (768, 9, 0.5, 0.5, 0.02, 0.2, 0.3, 0.1, "nnpp", 9),
 ]
 
 
@@ -210,7 +212,8 @@ def test_seeded_random_vs_oracle_bit_exact(csim, case):
                  dict(fuse=2, rows_per_chunk=64, prefetch=4), dict(fuse=2, xcd_swizzle=0),
                  dict(fuse=3), dict(fuse=3, rows_per_chunk=2, prefetch=4), dict(fuse=3, rows_per_chunk=1),
                  dict(fuse=4), dict(fuse=4, rows_per_chunk=5, prefetch=4), dict(fuse=4, xcd_swizzle=0),
-                 dict(fuse=4, rows_per_chunk=1)]:
+                 dict(fuse=4, rows_per_chunk=1), dict(fuse=4, wide=1), dict(fuse=3, wide=1, rows_per_chunk=3),
+                 dict(fuse=4, wide=1, rows_per_chunk=1), dict(fuse=3, wide=1, xcd_swizzle=0)]:
         got = run_gpu(csim, u0, dx, dy, D, vx, vy, dt, csim.bc_codes(bc), steps, opts)
         assert np.array_equal(got, want), (opts, float(np.abs(got - want).max()))
     got = run_gpu(csim, u0, dx, dy, D, vx, vy, dt, csim.bc_codes(bc), steps, None,
@@ -308,9 +311,9 @@ def _window_check(csim, nx, ny, D, vx, vy, dt, bc, steps, opts, nwin, seed):
     return got
 
 
-@pytest.mark.parametrize("fuse", [-1, 2, 3])
-def test_full_size_config2_4096_diffusion_periodic(csim, fuse):
-    got = _window_check(csim, 4096, 4096, 1.0, 0.0, 0.0, 0.1, "pppp", 9, dict(fuse=fuse), 12, 42)
+@pytest.mark.parametrize("fuse,wide", [(-1, 0), (2, 0), (3, 0), (4, 1), (3, 1)])
+def test_full_size_config2_4096_diffusion_periodic(csim, fuse, wide):
+    got = _window_check(csim, 4096, 4096, 1.0, 0.0, 0.0, 0.1, "pppp", 9, dict(fuse=fuse, wide=wide), 12, 42)
     assert np.isfinite(got).all()
 
 

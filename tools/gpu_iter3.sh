@@ -1,0 +1,12 @@
+#!/bin/bash
+set -x
+mkdir -p gpurun_out
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_comm.py -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; rc=$?; echo "pytest rc=$rc"
+tail -8 gpurun_out/pytest_gpu.log
+[ $rc -ne 0 ] && exit $rc
+timeout -k 10 600 python tools/sweep_variants.py --shape 16384x16384 4096x8192 8192x8192 --steps 25 --rounds 2 --variants 1 --ry 16 32 64 --pf 2 --fuse 3 4 --wide 0 1 > gpurun_out/sweep_wide.log 2>&1; echo "sweep rc=$?"
+grep "^{" gpurun_out/sweep_wide.log | python3 -c "
+import sys, json
+for ln in sys.stdin:
+    r = json.loads(ln); print(r['n'], r['ny'], 'ry', r['rows_per_chunk'], 'fuse', r['fuse'], 'wide', r['wide'], 'ms/step %.4f' % r['ms_med'], 'Mcell/s %.0f' % r['mcells'])
+"

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""tools/torus_bench.py — the multi-rank code path (deep-face pack/unpack, RCCL group exchange on
+the comm stream, frame tiles on the high-priority stream) timed on ONE GPU by linking a 1-rank
+communicator to itself in all 8 directions.  Tile shapes are the per-GPU tiles of the 16384^2
+strong-scaling run; the same tile without neighbours is timed next to it as the no-exchange bound."""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from __graft_entry__ import load_package  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shape", nargs="+", default=["8192x16384", "8192x8192", "4096x8192"])
+    ap.add_argument("--steps", type=int, default=101)
+    args = ap.parse_args()
+    csim = load_package()
+    csim.lib()
+    csim.set_device(0)
+    for sh in args.shape:
+        nx, ny = (int(v) for v in sh.split("x"))
+        for mode in ("single", "torus-overlap", "torus-serial"):
+            d = csim.decomp_init(1, 0, nx, ny)
+            if mode != "single":
+                for k in range(4):
+                    d.nbr[k] = 0
+            st = csim.Stepper(d, 1.0, 1.0, csim.bc_codes("dddd"))
+            if mode != "single":
+                st.comm_init(csim.comm_unique_id())
+                st.set_option("overlap", 1 if mode == "torus-overlap" else 0)
+            st.init_gaussian()
+            st.run(0.05, 0.1, 0.5, 0.25, 10)
+            st.sync()
+            best = 1e9
+            for _ in range(3):
+                t0 = time.perf_counter()
+                st.run(0.05, 0.1, 0.5, 0.25, args.steps)
+                st.sync()
+                best = min(best, time.perf_counter() - t0)
+            st.close()
+            print(json.dumps(dict(tile=sh, mode=mode, ms_per_step=best / args.steps * 1e3,
+                                  mcells=nx * ny * args.steps / best / 1e6)), flush=True)
+
+
+if __name__ == "__main__":
+    main()
