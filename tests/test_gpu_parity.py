@@ -325,6 +325,12 @@ def test_full_size_16384_windows(csim):
     _window_check(csim, 16384, 16384, 0.05, 0.5, 0.25, 0.1, "dnnd", 6, None, 10, 44)
 
 
+def test_full_size_config5_32768_neumann(csim):
+    """BASELINE configs[4]: 32768 x 32768, all-Neumann (2 x 8.6 GB on the device).  The reference is
+    decomposition-invariant, so the single-GPU field is what the 4 x 2 run must give as well."""
+    _window_check(csim, 32768, 32768, 0.05, 0.5, 0.25, 0.1, "nnnn", 5, None, 8, 45)
+
+
 def test_physics_sanity_like_reference_integration_tests(csim):
     """reference tests/simulation/integration/integration_{diffusion,advection}.cpp: the peak of
     a diffusing hotspot decreases and stays >= 0; an advected hotspot's centre of mass moves by
