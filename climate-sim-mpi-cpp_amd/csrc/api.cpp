@@ -137,6 +137,7 @@ struct csim_stepper {
     double* recv2[8]{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_edge2 = nullptr, ev_recv2 = nullptr;
     int fuse_cap = 1;     // deepest pass every rank of the decomposition can run (same on all ranks)
+    bool widths128 = false;  // every tile width of the decomposition is a multiple of 128
     int faces_depth = 0;  // recv2[] holds the neighbours' faces of `cur` of this depth (0 = none)
     SweepCfg cfg;
     int overlap = 1;
@@ -412,15 +413,16 @@ int csim_stepper_create(const csim_decomp* dec, double dx, double dy, const int 
             ok(hipMemset(s->send[k], 0, n)) && ok(hipMemset(s->recv[k], 0, n));
     }
     // The fused-pass depth must be decided identically on every rank (the face exchange is
-    // collective in effect): all tile widths multiples of 128, depth <= the smallest tile.
+    // collective in effect): depth <= the smallest tile of the decomposition.
     {
         const int px = dec->dims[0] > 0 ? dec->dims[0] : 1, py = dec->dims[1] > 0 ? dec->dims[1] : 1;
         const int gx = dec->nx_global > 0 ? dec->nx_global : s->nx, gy = dec->ny_global > 0 ? dec->ny_global : s->ny;
         const int bx = gx / px, rx = gx % px, by = gy / py;
-        const bool widths_ok = s->multi ? (bx > 0 && bx % WAVE_COLS == 0 && (bx + rx) % WAVE_COLS == 0)
-                                        : (s->nx % WAVE_COLS == 0);
+        // (the edge-lane-extras kernels additionally need every tile width to be a multiple of 128)
+        s->widths128 = s->multi ? (bx > 0 && bx % WAVE_COLS == 0 && (bx + rx) % WAVE_COLS == 0)
+                                : (s->nx % WAVE_COLS == 0);
         const int min_tile = s->multi ? std::min(bx, by) : MAX_FUSE;
-        s->fuse_cap = widths_ok ? std::max(1, std::min(MAX_FUSE, min_tile)) : 1;
+        s->fuse_cap = std::max(1, std::min(MAX_FUSE, min_tile));
     }
     // diagonal peers (only where both adjacent sides have neighbours)
     for (int k = 0; k < 4; ++k) s->nbr8[k] = dec->nbr[k];
@@ -790,6 +792,8 @@ static int pass_single(csim_stepper* s, const Phys& p, const GhostArgs& g) {
 // overlaps the rest of the sweep.
 static hipError_t launch_fused(csim_stepper* s, const Phys& p, const int kind[4], int T, int part,
                                hipStream_t st) {
+    if (s->cfg.multistep == MS_OVERLAP)
+        return launch_sweepO(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, s->cfg, kind, s->bc_value, T, part, st);
     if (T == 2)
         return launch_sweep2(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, s->cfg, kind, s->bc_value, part, st);
     return launch_sweepT(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, s->cfg, kind, s->bc_value, T, part, st);
@@ -849,7 +853,8 @@ int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy,
     // Up to MAX_FUSE steps per HBM pass where possible: width a multiple of 128 and, across
     // ranks, a tile at least as large as the face depth.
     int depth = std::min(s->fuse < 0 ? MAX_FUSE : s->fuse, s->fuse_cap);
-    const bool can_fuse = depth >= 2 && sweep2_supported(s->nx, s->cfg);
+    const bool dpp_family = s->cfg.variant == VAR_AUTO || s->cfg.variant == VAR_DPP;
+    const bool can_fuse = depth >= 2 && dpp_family && (s->cfg.multistep == MS_OVERLAP || s->widths128);
     if (s->multi && s->external) {
         // the caller carries the faces: one step (depth-1 faces) or one fused pass per call
         if (nsteps == 1 && !s->halo_fresh)
@@ -917,6 +922,12 @@ int csim_stepper_set_option(csim_stepper* s, const char* key, long value) {
     } else if (k == "prefetch") {
         CSIM_REQUIRE(value >= 0 && value <= 8, "prefetch must be 0..8");
         s->cfg.prefetch = static_cast<int>(value);
+    } else if (k == "multistep") {
+        CSIM_REQUIRE(value == MS_OVERLAP || value == MS_EXTRAS, "multistep must be 0 (overlap) or 1 (extras)");
+        s->cfg.multistep = static_cast<int>(value);
+    } else if (k == "stagger") {
+        CSIM_REQUIRE(value >= 0 && value <= 4096, "stagger must be 0..4096");
+        s->cfg.stagger = static_cast<int>(value);
     } else if (k == "wide") {
         s->cfg.wide = value != 0;
     } else if (k == "xcd_swizzle") {

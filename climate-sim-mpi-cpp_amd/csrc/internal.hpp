@@ -12,8 +12,8 @@
 // columns left of i = 0 / right of i = nx+1) exist as device-only ghost layers, which the
 // multi-step-per-pass sweeps read (as halo data on neighbour sides, as don't-care otherwise).
 //
-// pitch = LPAD + round_up(nx + 1, 128) + 16 doubles; for nx = 16384 that is 16544 doubles =
-// 132352 B, an odd multiple of 256 B, so vertically adjacent rows do not alias onto one HBM
+// pitch = LPAD + round_up(nx + 1, 128) + 128 doubles; for nx = 16384 that is 16656 doubles =
+// 133248 B, an odd multiple of 128 B, so vertically adjacent rows do not alias onto one HBM
 // channel.  Pads are zero and never written.
 #pragma once
 
@@ -31,7 +31,7 @@ constexpr int LPAD = 16;        // doubles in front of the first interior column
 constexpr int WAVE_COLS = 128;  // columns one wavefront covers per row (64 lanes x 2 doubles)
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
-inline int pitch_for(int nx) { return LPAD + round_up(nx + 1, WAVE_COLS) + 16; }
+inline int pitch_for(int nx) { return LPAD + round_up(nx + 1, WAVE_COLS) + WAVE_COLS; }
 
 void set_error(const std::string& msg);
 int fail(int code, const std::string& msg);
@@ -57,12 +57,16 @@ Phys make_phys(double dx, double dy, double D, double dt, double vx, double vy);
 
 // kernel variants of the fused sweep (option "variant")
 enum { VAR_AUTO = 0, VAR_DPP = 1, VAR_LDS = 2, VAR_NAIVE = 3 };
+// multi-step kernel families (option "multistep"): overlapped strips (default) or edge-lane extras
+enum { MS_OVERLAP = 0, MS_EXTRAS = 1 };
 
 struct SweepCfg {
     int variant = VAR_AUTO;
     int rows_per_chunk = 0;  // 0 = auto
     int prefetch = 0;        // 0 = auto (rows kept in flight per wavefront)
     int xcd_swizzle = 1;
+    int multistep = MS_OVERLAP;
+    int stagger = 0;         // T >= 3 sweeps: start offset between co-resident workgroups (x 64 cycles)
     int wide = 0;            // T >= 3 sweeps: 256-column strips per wavefront (needs nx % 256 == 0)
 };
 
@@ -78,6 +82,9 @@ hipError_t launch_sweep2(const double* in, double* out, int nx, int ny, int pitc
                          hipStream_t st);
 // T = 3 or 4 time steps per pass (same kind[] / part conventions as launch_sweep2)
 hipError_t launch_sweepT(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
+                         const SweepCfg& cfg, const int kind[4], double value, int T, int part,
+                         hipStream_t st);
+hipError_t launch_sweepO(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
                          const SweepCfg& cfg, const int kind[4], double value, int T, int part,
                          hipStream_t st);
 constexpr int MAX_FUSE = 4;       // deepest temporal blocking

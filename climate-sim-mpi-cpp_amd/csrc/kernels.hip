@@ -490,9 +490,16 @@ template <int DIV, int T, int SX, int SY>
 __global__ __launch_bounds__(256) void k_sweepT_dpp(const double* __restrict__ in,
                                                     double* __restrict__ out, int nx, int ny,
                                                     int pitch, int ry, int nwgx, int nchunks,
-                                                    int part, int swz, Phys p, Bc2 bc) {
+                                                    int part, int swz, int stagger, Phys p, Bc2 bc) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    if (stagger > 0) {
+        // Co-resident workgroups of one CU start a fraction of a row-iteration apart, so that the
+        // wavefronts sharing a SIMD do not hit their load and arithmetic phases in lockstep
+        // (matters when the whole launch is a single round of wavefronts: small per-GPU tiles).
+        const int slot = ((blockIdx.x >> 3) >> 5) & 3;
+        for (int k = 0; k < slot * stagger; ++k) __builtin_amdgcn_s_sleep(1);
+    }
     // part 0: every tile; 1: frame tiles only; 2: all but the frame tiles (see k_sweep2_dpp)
     int wgx, chunk, side = -1;
     if (part == 1 && nchunks >= 2) {
@@ -528,6 +535,180 @@ __global__ __launch_bounds__(256) void k_sweepT_dpp(const double* __restrict__ i
         sweepT_march<DIV, T, true, SX, SY>(in, out, ny, pitch, jb, je, c0, lane, kl, kr, p, bc);
     else
         sweepT_march<DIV, T, false, SX, SY>(in, out, ny, pitch, jb, je, c0, lane, kl, kr, p, bc);
+}
+
+// -------------------------------------------------------------------------------------------
+// VAR_OVERLAP — T time steps per pass with OVERLAPPED strips (the default multi-step kernel).
+// A wavefront loads 128 consecutive columns (2 per lane, 16-byte aligned) but only the inner
+// 128 - 2*TP of them (TP = T rounded up to even) are its outputs: level l is valid on local
+// columns [l, 127 - l], so no extra-column bookkeeping is needed at all — the W/E neighbours are
+// plain DPP lane shifts (the invalid outermost lanes simply compute don't-care values) and the
+// strips overlap by 2*TP columns (6 % redundant work at T = 4) instead of paying one extra
+// wave-wide cell update per level (50 %).  A row of a level is ONE double2 per lane, so the whole
+// T-level pipeline fits in ~80 VGPRs.  Row pipeline, ghost-row rules and tile split are those of
+// k_sweepT_dpp; ghost COLUMNS are ordinary lanes here, patched by the boundary rule on wavefronts
+// that contain a physical edge.  Any nx works (no multiple-of-128 requirement).
+// -------------------------------------------------------------------------------------------
+__device__ __forceinline__ double shift_from_prev(double src) {  // lane i <- lane i-1 (lane 0: 0)
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(src), 0x138, 0xf, 0xf, true);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(src), 0x138, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double shift_from_next(double src) {  // lane i <- lane i+1 (lane 63: 0)
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(src), 0x130, 0xf, 0xf, true);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(src), 0x130, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+template <int T>
+struct OverlapGeom {
+    static constexpr int TP = 2 * ((T + 1) / 2);       // T rounded up to even
+    static constexpr int STRIDE = WAVE_COLS - 2 * TP;  // output columns per wavefront
+};
+
+template <int DIV, int T, bool EDGE, int SX, int SY>
+__device__ __forceinline__ void sweepO_march(const double* __restrict__ in, double* __restrict__ out,
+                                             int nx, int ny, int pitch, int jb, int je, int g0, int lane,
+                                             int kl, int kr, const Phys& p, const Bc2& bc) {
+    constexpr int TP = OverlapGeom<T>::TP;
+    constexpr int STRIDE = OverlapGeom<T>::STRIDE;
+    // this lane's two columns, 0-based interior index (-1 = left ghost, nx = right ghost)
+    const int gx = g0 + 2 * lane, gy = gx + 1;
+    const ptrdiff_t xoff = LPAD + gx;
+    const int kb = bc.kind[CSIM_BOTTOM], kt = bc.kind[CSIM_TOP];  // 3 = neighbour rank: plain stencil
+    // output lanes: local columns [TP, TP + STRIDE), clipped to the interior
+    const bool out_lane = 2 * lane >= TP && 2 * lane < TP + STRIDE && gx < nx;
+    const int nvalid = nx - gx;
+
+    auto load = [&](int j) {
+        return *reinterpret_cast<const double2*>(in + static_cast<ptrdiff_t>(j) * pitch + xoff);
+    };
+
+    const int r_first = jb - (T - 1);
+    const int niter = (je - jb + 1) + 2 * (T - 1);
+    const int last_row = r_first + niter;
+    double2 L0[6];
+    double2 L[T][3];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        L0[q] = make_double2(0.0, 0.0);
+        const int row = r_first - 1 + q;
+        if (row <= last_row) L0[q] = load(row);
+    }
+#pragma unroll
+    for (int l = 0; l < T; ++l)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) L[l][q] = make_double2(0.0, 0.0);
+
+    for (int k0 = 0; k0 < niter; k0 += 6) {
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int k = k0 + u;
+            if (k < niter) {  // wave-uniform
+                const int r = r_first + k;
+#pragma unroll
+                for (int l = 1; l <= T; ++l) {
+                    const int rho = r - l + 1;
+                    const double2 s = (l == 1) ? L0[u % 6] : L[l - 1][(u + 1) % 3];
+                    const double2 c = (l == 1) ? L0[(u + 1) % 6] : L[l - 1][(u + 2) % 3];
+                    const double2 n = (l == 1) ? L0[(u + 2) % 6] : L[l - 1][u % 3];
+                    double2 o;
+                    bool ghost_row = false;
+                    if (EDGE && l < T) {
+                        const bool gb = rho == 0 && kb != 3, gt = rho == ny + 1 && kt != 3;
+                        ghost_row = gb || gt;
+                        if (ghost_row) {
+                            const int kk = gb ? kb : kt;
+                            if (kk == CSIM_BC_DIRICHLET)
+                                o = make_double2(bc.value, bc.value);
+                            else if (kk == CSIM_BC_PERIODIC)
+                                o = c;
+                            else if (gt)
+                                o = L[l][(u + 2) % 3];  // Neumann top: row ny of this level
+                            else
+                                o = make_double2(0.0, 0.0);  // Neumann bottom: patched below
+                        }
+                    }
+                    if (!ghost_row) {
+                        const double Wx = shift_from_prev(c.y);
+                        const double Ey = shift_from_next(c.x);
+                        o.x = cell<DIV, SX, SY>(c.x, Wx, c.y, s.x, n.x, p);
+                        o.y = cell<DIV, SX, SY>(c.y, c.x, Ey, s.y, n.y, p);
+                        if (EDGE && l < T) {  // ghost columns of this level on a physical edge
+                            if (kl != 3 && gy == -1)
+                                o.y = kl == CSIM_BC_DIRICHLET ? bc.value : kl == CSIM_BC_PERIODIC ? c.y : 0.0;
+                            if (kr != 3 && gx == nx)
+                                o.x = kr == CSIM_BC_DIRICHLET ? bc.value : kr == CSIM_BC_PERIODIC ? c.x : 0.0;
+                            if (kr != 3 && gy == nx)
+                                o.y = kr == CSIM_BC_DIRICHLET ? bc.value : kr == CSIM_BC_PERIODIC ? c.y : o.x;
+                            if (kl == CSIM_BC_NEUMANN) {  // left ghost (.y of its lane) := column 0 (.x of the next lane)
+                                const double nb = shift_from_next(o.x);
+                                if (gy == -1) o.y = nb;
+                            }
+                            if (kr == CSIM_BC_NEUMANN) {  // right ghost held in .x := column nx-1 (.y of the previous lane)
+                                const double pb = shift_from_prev(o.y);
+                                if (gx == nx) o.x = pb;
+                            }
+                        }
+                    }
+                    if (l < T) {
+                        if (EDGE && rho == 1 && kb == CSIM_BC_NEUMANN) L[l][(u + 2) % 3] = o;  // ghost row 0 := row 1
+                        L[l][u % 3] = o;
+                    } else if (rho >= jb && out_lane) {
+                        store_pair(out + static_cast<ptrdiff_t>(rho) * pitch + xoff, o.x, o.y, nvalid);
+                    }
+                }
+                const int rn = r + 5;
+                if (rn <= last_row) L0[u % 6] = load(rn);
+            }
+        }
+    }
+}
+
+template <int DIV, int T, int SX, int SY>
+__global__ __launch_bounds__(256) void k_sweepO_dpp(const double* __restrict__ in,
+                                                    double* __restrict__ out, int nx, int ny,
+                                                    int pitch, int ry, int nstrips, int nwgx,
+                                                    int nchunks, int part, int swz, Phys p, Bc2 bc) {
+    constexpr int TP = OverlapGeom<T>::TP;
+    constexpr int STRIDE = OverlapGeom<T>::STRIDE;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    int wgx, chunk, side = -1;
+    if (part == 1 && nchunks >= 2) {
+        const int b = blockIdx.x;
+        if (b < 2 * nwgx) {
+            chunk = b < nwgx ? 0 : nchunks - 1;
+            wgx = b < nwgx ? b : b - nwgx;
+        } else {
+            chunk = 1 + ((b - 2 * nwgx) >> 1);
+            side = (b - 2 * nwgx) & 1;
+            wgx = side ? nwgx - 1 : 0;
+        }
+    } else {
+        const int lin = xcd_remap(blockIdx.x, gridDim.x, swz);
+        wgx = lin % nwgx;
+        chunk = lin / nwgx;
+    }
+    const int strip = wgx * 4 + wave;
+    if (strip >= nstrips) return;  // wave-uniform
+    const bool first = strip == 0, last = strip == nstrips - 1;
+    if (side == 0 && !first) return;
+    if (side == 1 && !last) return;
+    if (part == 2 && (nchunks < 2 || chunk == 0 || chunk == nchunks - 1 || first || last)) return;
+    const int jb = chunk * ry + 1;
+    const int je = min(jb + ry - 1, ny);
+    const int g0 = strip * STRIDE - TP;
+    // a strip meets the left ghost column iff it is the first one; the right ghost column (index
+    // nx) lies inside every strip whose 128 loaded columns reach it
+    const int kl = first ? bc.kind[CSIM_LEFT] : 3;
+    const int kr = g0 + WAVE_COLS > nx ? bc.kind[CSIM_RIGHT] : 3;
+    const bool edge = kl != 3 || kr != 3 || (bc.kind[CSIM_BOTTOM] != 3 && jb - (T - 1) < 1) ||
+                      (bc.kind[CSIM_TOP] != 3 && je + (T - 1) > ny);
+    if (edge)
+        sweepO_march<DIV, T, true, SX, SY>(in, out, nx, ny, pitch, jb, je, g0, lane, kl, kr, p, bc);
+    else
+        sweepO_march<DIV, T, false, SX, SY>(in, out, nx, ny, pitch, jb, je, g0, lane, kl, kr, p, bc);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -1242,6 +1423,9 @@ static hipError_t sweepT_div(const double* in, double* out, int nx, int ny, int 
 #define CSIM_LAUNCH_T(KERNEL, SXV, SYV)                                                               \
     hipLaunchKernelGGL((KERNEL<DIV, T, SXV, SYV>), grid, block, 0, st, in, out, nx, ny, pitch, ry, nwgx, \
                        nchunks, part, sw, p, bc)
+#define CSIM_LAUNCH_TS(KERNEL, SXV, SYV)                                                              \
+    hipLaunchKernelGGL((KERNEL<DIV, T, SXV, SYV>), grid, block, 0, st, in, out, nx, ny, pitch, ry, nwgx, \
+                       nchunks, part, sw, cfg.stagger, p, bc)
     if (wide) {
         switch (sign) {
             case 3: CSIM_LAUNCH_T(k_sweepTw_dpp, 1, 1); break;
@@ -1251,14 +1435,71 @@ static hipError_t sweepT_div(const double* in, double* out, int nx, int ny, int 
         }
     } else {
         switch (sign) {
-            case 3: CSIM_LAUNCH_T(k_sweepT_dpp, 1, 1); break;
-            case 2: CSIM_LAUNCH_T(k_sweepT_dpp, 1, 0); break;
-            case 1: CSIM_LAUNCH_T(k_sweepT_dpp, 0, 1); break;
-            default: CSIM_LAUNCH_T(k_sweepT_dpp, 0, 0); break;
+            case 3: CSIM_LAUNCH_TS(k_sweepT_dpp, 1, 1); break;
+            case 2: CSIM_LAUNCH_TS(k_sweepT_dpp, 1, 0); break;
+            case 1: CSIM_LAUNCH_TS(k_sweepT_dpp, 0, 1); break;
+            default: CSIM_LAUNCH_TS(k_sweepT_dpp, 0, 0); break;
         }
     }
 #undef CSIM_LAUNCH_T
+#undef CSIM_LAUNCH_TS
     return hipGetLastError();
+}
+
+template <int DIV, int T>
+static hipError_t sweepO_div(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
+                             const SweepCfg& cfg, const Bc2& bc, int part, hipStream_t st) {
+    constexpr int STRIDE = OverlapGeom<T>::STRIDE;
+    const int nstrips = cdiv(nx, STRIDE);
+    int ry = cfg.rows_per_chunk;
+    if (ry <= 0) {
+        ry = 64;
+        while (ry > 16 && static_cast<long>(nstrips) * cdiv(ny, ry) < 8192) ry >>= 1;
+    }
+    if (ry > ny) ry = ny;
+    const int nchunks = cdiv(ny, ry);
+    const int nwgx = cdiv(nstrips, 4);
+    int nblocks = nwgx * nchunks;
+    if (part == 1 && nchunks >= 2) nblocks = 2 * nwgx + 2 * (nchunks - 2);
+    if (part == 2 && nchunks < 3) return hipSuccess;  // every tile is a frame tile
+    const dim3 grid(nblocks), block(256);
+    const int sw = cfg.xcd_swizzle;
+    const int sign = (p.vx >= 0.0 ? 2 : 0) + (p.vy >= 0.0 ? 1 : 0);
+#define CSIM_LAUNCH_O(SXV, SYV)                                                                        \
+    hipLaunchKernelGGL((k_sweepO_dpp<DIV, T, SXV, SYV>), grid, block, 0, st, in, out, nx, ny, pitch, ry, \
+                       nstrips, nwgx, nchunks, part, sw, p, bc)
+    switch (sign) {
+        case 3: CSIM_LAUNCH_O(1, 1); break;
+        case 2: CSIM_LAUNCH_O(1, 0); break;
+        case 1: CSIM_LAUNCH_O(0, 1); break;
+        default: CSIM_LAUNCH_O(0, 0); break;
+    }
+#undef CSIM_LAUNCH_O
+    return hipGetLastError();
+}
+
+template <int T>
+static hipError_t sweepO_T(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
+                           const SweepCfg& cfg, const Bc2& bc, int part, hipStream_t st) {
+    switch (p.div_mode) {
+        case 0: return sweepO_div<0, T>(in, out, nx, ny, pitch, p, cfg, bc, part, st);
+        case 1: return sweepO_div<1, T>(in, out, nx, ny, pitch, p, cfg, bc, part, st);
+        default: return sweepO_div<2, T>(in, out, nx, ny, pitch, p, cfg, bc, part, st);
+    }
+}
+
+// overlapped-strip multi-step sweep, T = 2..4 (same kind[] / part conventions as launch_sweep2)
+hipError_t launch_sweepO(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
+                         const SweepCfg& cfg, const int kind[4], double value, int T, int part,
+                         hipStream_t st) {
+    Bc2 bc;
+    for (int s = 0; s < 4; ++s) bc.kind[s] = kind[s];
+    bc.value = value;
+    switch (T) {
+        case 2: return sweepO_T<2>(in, out, nx, ny, pitch, p, cfg, bc, part, st);
+        case 3: return sweepO_T<3>(in, out, nx, ny, pitch, p, cfg, bc, part, st);
+        default: return sweepO_T<4>(in, out, nx, ny, pitch, p, cfg, bc, part, st);
+    }
 }
 
 // T = 3 or 4 time steps per pass; kind[s] = CSIM_BC_* on physical sides, 3 on neighbour sides

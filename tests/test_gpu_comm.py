@@ -72,6 +72,7 @@ def test_self_exchange_torus(csim, sides, bc, overlap, shape):
     st.comm_init(csim.comm_unique_id())
     st.set_option("overlap", overlap)
     st.set_option("wide", 1 if wide else 0)
+    st.set_option("multistep", 1 if wide else 0)
     st.upload(u0)
     st.run(D, dt, vx, vy, 3)
     st.run(D, dt, vx, vy, steps - 3)

@@ -22,7 +22,8 @@ RUN_FILES = sorted(glob.glob(os.path.join(GOLDEN, "run_*.npz")))
 VARIANT_CFGS = [dict(variant=1, prefetch=1), dict(variant=1, prefetch=2), dict(variant=1, prefetch=4),
                 dict(variant=1, prefetch=8, rows_per_chunk=7), dict(variant=1, rows_per_chunk=1),
                 dict(variant=1, xcd_swizzle=0), dict(variant=2), dict(variant=2, rows_per_chunk=5),
-                dict(variant=3), dict(fuse=0), dict(fuse=2), dict(fuse=3), dict(fuse=4)]
+                dict(variant=3), dict(fuse=0), dict(fuse=2), dict(fuse=3), dict(fuse=4),
+                dict(fuse=4, rows_per_chunk=3), dict(fuse=3, rows_per_chunk=1), dict(fuse=4, multistep=1)]
 
 
 @pytest.fixture(scope="module")
@@ -213,7 +214,9 @@ def test_seeded_random_vs_oracle_bit_exact(csim, case):
                  dict(fuse=3), dict(fuse=3, rows_per_chunk=2, prefetch=4), dict(fuse=3, rows_per_chunk=1),
                  dict(fuse=4), dict(fuse=4, rows_per_chunk=5, prefetch=4), dict(fuse=4, xcd_swizzle=0),
                  dict(fuse=4, rows_per_chunk=1), dict(fuse=4, wide=1), dict(fuse=3, wide=1, rows_per_chunk=3),
-                 dict(fuse=4, wide=1, rows_per_chunk=1), dict(fuse=3, wide=1, xcd_swizzle=0)]:
+                 dict(fuse=4, wide=1, rows_per_chunk=1), dict(fuse=3, wide=1, xcd_swizzle=0),
+                 dict(fuse=2, multistep=1), dict(fuse=3, multistep=1, rows_per_chunk=2),
+                 dict(fuse=4, multistep=1), dict(fuse=4, multistep=1, rows_per_chunk=5)]:
         got = run_gpu(csim, u0, dx, dy, D, vx, vy, dt, csim.bc_codes(bc), steps, opts)
         assert np.array_equal(got, want), (opts, float(np.abs(got - want).max()))
     got = run_gpu(csim, u0, dx, dy, D, vx, vy, dt, csim.bc_codes(bc), steps, None,
@@ -311,9 +314,10 @@ def _window_check(csim, nx, ny, D, vx, vy, dt, bc, steps, opts, nwin, seed):
     return got
 
 
-@pytest.mark.parametrize("fuse,wide", [(-1, 0), (2, 0), (3, 0), (4, 1), (3, 1)])
-def test_full_size_config2_4096_diffusion_periodic(csim, fuse, wide):
-    got = _window_check(csim, 4096, 4096, 1.0, 0.0, 0.0, 0.1, "pppp", 9, dict(fuse=fuse, wide=wide), 12, 42)
+@pytest.mark.parametrize("fuse,wide,ms", [(-1, 0, 0), (2, 0, 0), (3, 0, 0), (4, 0, 1), (4, 1, 1), (3, 1, 1)])
+def test_full_size_config2_4096_diffusion_periodic(csim, fuse, wide, ms):
+    got = _window_check(csim, 4096, 4096, 1.0, 0.0, 0.0, 0.1, "pppp", 9,
+                        dict(fuse=fuse, wide=wide, multistep=ms), 12, 42)
     assert np.isfinite(got).all()
 
 

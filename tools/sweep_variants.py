@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--swz", type=int, nargs="+", default=[1])
     ap.add_argument("--fuse", type=int, nargs="+", default=[0, 2, 3, 4])
     ap.add_argument("--wide", type=int, nargs="+", default=[0])
+    ap.add_argument("--stagger", type=int, nargs="+", default=[0])
+    ap.add_argument("--multistep", type=int, nargs="+", default=[0])
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     csim = load_package()
@@ -38,9 +40,11 @@ def main():
         cfgs = []
         for v in args.variants:
             if v == 1:
-                cfgs += [dict(variant=1, rows_per_chunk=r, prefetch=p, xcd_swizzle=s, fuse=f, wide=w)
-                         for r, p, s, f, w in itertools.product(args.ry, args.pf, args.swz, args.fuse, args.wide)
-                         if not (w and f < 3)]
+                cfgs += [dict(variant=1, rows_per_chunk=r, prefetch=p, xcd_swizzle=s, fuse=f, wide=w, stagger=g,
+                              multistep=m)
+                         for r, p, s, f, w, g, m in itertools.product(args.ry, args.pf, args.swz, args.fuse,
+                                                                      args.wide, args.stagger, args.multistep)
+                         if not (w and (f < 3 or m == 0))]
             elif v == 2:
                 cfgs += [dict(variant=2, rows_per_chunk=r, prefetch=0, xcd_swizzle=s, fuse=0)
                          for r, s in itertools.product(args.ry, args.swz)]
