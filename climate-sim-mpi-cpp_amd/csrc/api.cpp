@@ -662,7 +662,7 @@ static bool depth_ok(const csim_stepper* s, int depth) {
 
 int csim_stepper_faces_neighbors(const csim_stepper* s, int depth, int peers[8], int lengths[8]) {
     CSIM_REQUIRE(s && peers && lengths, "null argument");
-    CSIM_REQUIRE(depth_ok(s, depth), "face depth must be 2..4 and fit the tile");
+    CSIM_REQUIRE(depth_ok(s, depth), "face depth must be 2..6 and fit the tile");
     for (int d = 0; d < 8; ++d) {
         peers[d] = s->nbr8[d];
         lengths[d] = s->nbr8[d] >= 0 ? static_cast<int>(s->face_len(d, depth)) : 0;
@@ -672,7 +672,7 @@ int csim_stepper_faces_neighbors(const csim_stepper* s, int depth, int peers[8],
 
 int csim_stepper_faces_pack(csim_stepper* s, int depth, double* const host_send[8]) {
     CSIM_REQUIRE(s && host_send, "null argument");
-    CSIM_REQUIRE(depth_ok(s, depth), "face depth must be 2..4 and fit the tile");
+    CSIM_REQUIRE(depth_ok(s, depth), "face depth must be 2..6 and fit the tile");
     if (!s->multi) return CSIM_OK;
     CSIM_HIP(launch_halo2_pack(s->cur, s->nx, s->ny, s->pitch, depth, s->send2, s->s_comp));
     for (int d = 0; d < 8; ++d) {
@@ -687,7 +687,7 @@ int csim_stepper_faces_pack(csim_stepper* s, int depth, double* const host_send[
 
 int csim_stepper_faces_unpack(csim_stepper* s, int depth, const double* const host_recv[8]) {
     CSIM_REQUIRE(s && host_recv, "null argument");
-    CSIM_REQUIRE(depth_ok(s, depth), "face depth must be 2..4 and fit the tile");
+    CSIM_REQUIRE(depth_ok(s, depth), "face depth must be 2..6 and fit the tile");
     if (!s->multi) return CSIM_OK;
     for (int d = 0; d < 8; ++d) {
         if (s->nbr8[d] < 0) continue;
@@ -853,6 +853,7 @@ int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy,
     // Up to MAX_FUSE steps per HBM pass where possible: width a multiple of 128 and, across
     // ranks, a tile at least as large as the face depth.
     int depth = std::min(s->fuse < 0 ? MAX_FUSE : s->fuse, s->fuse_cap);
+    if (s->cfg.multistep == MS_EXTRAS) depth = std::min(depth, 4);
     const bool dpp_family = s->cfg.variant == VAR_AUTO || s->cfg.variant == VAR_DPP;
     const bool can_fuse = depth >= 2 && dpp_family && (s->cfg.multistep == MS_OVERLAP || s->widths128);
     if (s->multi && s->external) {
@@ -938,7 +939,7 @@ int csim_stepper_set_option(csim_stepper* s, const char* key, long value) {
         s->external = value != 0;
         s->halo_fresh = false;
     } else if (k == "fuse") {
-        CSIM_REQUIRE(value >= -1 && value <= MAX_FUSE, "fuse must be -1 (auto) or 0..4");
+        CSIM_REQUIRE(value >= -1 && value <= MAX_FUSE, "fuse must be -1 (auto) or 0..6");
         s->fuse = static_cast<int>(value);
     } else if (k == "profile") {
         s->profile = value != 0;
@@ -951,7 +952,7 @@ int csim_stepper_set_option(csim_stepper* s, const char* key, long value) {
 int csim_stepper_kernel_time(csim_stepper* s, int steps_per_launch, double* total_ms,
                              long* launches) {
     CSIM_REQUIRE(s && total_ms && launches, "null argument");
-    CSIM_REQUIRE(steps_per_launch >= 1 && steps_per_launch <= MAX_FUSE, "steps_per_launch must be 1..4");
+    CSIM_REQUIRE(steps_per_launch >= 1 && steps_per_launch <= MAX_FUSE, "steps_per_launch must be 1..6");
     int rc = prof_fold(s);
     if (rc) return rc;
     *total_ms = s->prof_ms[steps_per_launch];

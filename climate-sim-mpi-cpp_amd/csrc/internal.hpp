@@ -8,7 +8,7 @@
 //
 //     | 15 unused | ghost i=0 | interior i=1..nx (128-B aligned) | ghost i=nx+1 | pad ... |
 //
-// `view` points GHOST_EXTRA rows into the allocation: rows -3..-1 and ny+2..ny+4 (and the pad
+// `view` points GHOST_EXTRA rows into the allocation: rows -5..-1 and ny+2..ny+6 (and the pad
 // columns left of i = 0 / right of i = nx+1) exist as device-only ghost layers, which the
 // multi-step-per-pass sweeps read (as halo data on neighbour sides, as don't-care otherwise).
 //
@@ -87,8 +87,8 @@ hipError_t launch_sweepT(const double* in, double* out, int nx, int ny, int pitc
 hipError_t launch_sweepO(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
                          const SweepCfg& cfg, const int kind[4], double value, int T, int part,
                          hipStream_t st);
-constexpr int MAX_FUSE = 4;       // deepest temporal blocking
-constexpr int GHOST_EXTRA = 3;    // device-only ghost layers beyond the reference's one (= MAX_FUSE-1)
+constexpr int MAX_FUSE = 6;       // deepest temporal blocking (overlapped-strip kernel; the extras kernels stop at 4)
+constexpr int GHOST_EXTRA = 5;    // device-only ghost layers beyond the reference's one (= MAX_FUSE-1)
 // faces of depth H = 2..4 (8 directions: L R B T BL BR TL TR; nullptr = no neighbour there);
 // sizes H*(ny+2) (L,R), H*(nx+2) (B,T), H*H (corners)
 hipError_t launch_halo2_pack(const double* f, int nx, int ny, int pitch, int depth,

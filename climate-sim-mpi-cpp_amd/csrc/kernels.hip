@@ -1488,7 +1488,7 @@ static hipError_t sweepO_T(const double* in, double* out, int nx, int ny, int pi
     }
 }
 
-// overlapped-strip multi-step sweep, T = 2..4 (same kind[] / part conventions as launch_sweep2)
+// overlapped-strip multi-step sweep, T = 2..6 (same kind[] / part conventions as launch_sweep2)
 hipError_t launch_sweepO(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
                          const SweepCfg& cfg, const int kind[4], double value, int T, int part,
                          hipStream_t st) {
@@ -1498,7 +1498,9 @@ hipError_t launch_sweepO(const double* in, double* out, int nx, int ny, int pitc
     switch (T) {
         case 2: return sweepO_T<2>(in, out, nx, ny, pitch, p, cfg, bc, part, st);
         case 3: return sweepO_T<3>(in, out, nx, ny, pitch, p, cfg, bc, part, st);
-        default: return sweepO_T<4>(in, out, nx, ny, pitch, p, cfg, bc, part, st);
+        case 4: return sweepO_T<4>(in, out, nx, ny, pitch, p, cfg, bc, part, st);
+        case 5: return sweepO_T<5>(in, out, nx, ny, pitch, p, cfg, bc, part, st);
+        default: return sweepO_T<6>(in, out, nx, ny, pitch, p, cfg, bc, part, st);
     }
 }
 

@@ -125,7 +125,7 @@ int csim_stepper_init_gaussian(csim_stepper* s, double A, double sigma_frac, dou
  * next csim_stepper_run(.., 1).  One step per run call in this mode. */
 int csim_stepper_halo_pack(csim_stepper* s, double* const host_send[4]);
 int csim_stepper_halo_unpack(csim_stepper* s, const double* const host_recv[4]);
-/* deep-face flavour for csim_stepper_run(.., depth) (ONE fused pass of depth = 2..4 steps) in
+/* deep-face flavour for csim_stepper_run(.., depth) (ONE fused pass of depth = 2..6 steps) in
  * external mode: directions 0..7 = left, right, bottom, top, bottom-left, bottom-right, top-left,
  * top-right; _neighbors gives the peer rank (or CSIM_NO_NEIGHBOR) and the face length in doubles
  * per direction (depth*(ny+2), depth*(nx+2), depth*depth).  The face packed for direction d must be
@@ -143,12 +143,13 @@ int csim_stepper_minmax(csim_stepper* s, double out_min_max[2]);
 int csim_stepper_sum(csim_stepper* s, double* out);
 /* tuning / measurement knobs; unknown keys give CSIM_ERR_ARG.
  *   "variant" kernel family (0 auto, 1 dpp, 2 lds, 3 naive), "rows_per_chunk", "prefetch",
- *   "xcd_swizzle" (0/1), "fuse" (time steps per HBM pass: -1 auto, 0/1 off, 2..4), "overlap" (0/1: halo
+ *   "xcd_swizzle" (0/1), "fuse" (time steps per HBM pass: -1 auto, 0/1 off, 2..6), "multistep" (0 overlapped strips,
+ *   1 edge-lane extras), "wide", "stagger", "overlap" (0/1: halo
  *   exchange on the second stream), "external_halo" (0/1), "profile" (0/1) */
 int csim_stepper_set_option(csim_stepper* s, const char* key, long value);
 /* with option "profile"=1: HIP-event time (on the compute stream) and count of the sweep
  * launches since the last reset, per kernel kind: steps_per_launch = 1 selects the single-step
- * kernel, 2..4 the kernels that advance that many time steps per HBM pass */
+ * kernel, 2..6 the kernels that advance that many time steps per HBM pass */
 int csim_stepper_kernel_time(csim_stepper* s, int steps_per_launch, double* total_ms,
                              long* launches);
 int csim_stepper_reset_timers(csim_stepper* s);

@@ -114,7 +114,7 @@ def main():
             st.run(m["D"], dt, m["vx"], m["vy"], 1)
         local = st.download()
         st.close()
-    elif args.engine.startswith("hip-external") and args.engine[-1] in "234":
+    elif args.engine.startswith("hip-external") and args.engine[-1] in "23456":
         # `depth` reference steps per call (one fused HBM pass) with deep faces, then single steps
         depth = int(args.engine[-1])
         csim.lib()

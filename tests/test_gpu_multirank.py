@@ -18,10 +18,10 @@ def test_hip_stepper_multirank_one_gpu(world):
         assert rc == 0 and "ok=True" in out, (os.path.basename(case), out[-3000:])
 
 
-@pytest.mark.parametrize("depth", [2, 3, 4])
+@pytest.mark.parametrize("depth", [2, 3, 4, 6])
 @pytest.mark.parametrize("world", [2, 3, 4])
 def test_hip_stepper_fused_passes_multirank_one_gpu(world, depth):
-    """2/3/4 steps per pass across ranks: deep faces incl. the diagonal corner blocks"""
+    """2..6 steps per pass across ranks: deep faces incl. the diagonal corner blocks"""
     cases = [c for c in cases_with(world) if "run_fused" in c]
     assert cases
     for case in cases:

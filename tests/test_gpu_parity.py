@@ -23,7 +23,8 @@ VARIANT_CFGS = [dict(variant=1, prefetch=1), dict(variant=1, prefetch=2), dict(v
                 dict(variant=1, prefetch=8, rows_per_chunk=7), dict(variant=1, rows_per_chunk=1),
                 dict(variant=1, xcd_swizzle=0), dict(variant=2), dict(variant=2, rows_per_chunk=5),
                 dict(variant=3), dict(fuse=0), dict(fuse=2), dict(fuse=3), dict(fuse=4),
-                dict(fuse=4, rows_per_chunk=3), dict(fuse=3, rows_per_chunk=1), dict(fuse=4, multistep=1)]
+                dict(fuse=4, rows_per_chunk=3), dict(fuse=3, rows_per_chunk=1), dict(fuse=4, multistep=1),
+                dict(fuse=5), dict(fuse=6), dict(fuse=6, rows_per_chunk=2), dict(fuse=5, rows_per_chunk=1)]
 
 
 @pytest.fixture(scope="module")
@@ -215,6 +216,8 @@ def test_seeded_random_vs_oracle_bit_exact(csim, case):
                  dict(fuse=4), dict(fuse=4, rows_per_chunk=5, prefetch=4), dict(fuse=4, xcd_swizzle=0),
                  dict(fuse=4, rows_per_chunk=1), dict(fuse=4, wide=1), dict(fuse=3, wide=1, rows_per_chunk=3),
                  dict(fuse=4, wide=1, rows_per_chunk=1), dict(fuse=3, wide=1, xcd_swizzle=0),
+                 dict(fuse=5), dict(fuse=6), dict(fuse=6, rows_per_chunk=3), dict(fuse=5, rows_per_chunk=1),
+                 dict(fuse=6, xcd_swizzle=0, rows_per_chunk=7),
                  dict(fuse=2, multistep=1), dict(fuse=3, multistep=1, rows_per_chunk=2),
                  dict(fuse=4, multistep=1), dict(fuse=4, multistep=1, rows_per_chunk=5)]:
         got = run_gpu(csim, u0, dx, dy, D, vx, vy, dt, csim.bc_codes(bc), steps, opts)
@@ -314,25 +317,26 @@ def _window_check(csim, nx, ny, D, vx, vy, dt, bc, steps, opts, nwin, seed):
     return got
 
 
-@pytest.mark.parametrize("fuse,wide,ms", [(-1, 0, 0), (2, 0, 0), (3, 0, 0), (4, 0, 1), (4, 1, 1), (3, 1, 1)])
+@pytest.mark.parametrize("fuse,wide,ms", [(-1, 0, 0), (2, 0, 0), (3, 0, 0), (4, 0, 0), (5, 0, 0), (4, 0, 1),
+                                          (4, 1, 1), (3, 1, 1)])
 def test_full_size_config2_4096_diffusion_periodic(csim, fuse, wide, ms):
-    got = _window_check(csim, 4096, 4096, 1.0, 0.0, 0.0, 0.1, "pppp", 9,
+    got = _window_check(csim, 4096, 4096, 1.0, 0.0, 0.0, 0.1, "pppp", 14,
                         dict(fuse=fuse, wide=wide, multistep=ms), 12, 42)
     assert np.isfinite(got).all()
 
 
 def test_full_size_config3_8192_dirichlet(csim):
-    _window_check(csim, 8192, 8192, 0.05, 0.5, 0.25, 0.1, "dddd", 6, None, 12, 43)
+    _window_check(csim, 8192, 8192, 0.05, 0.5, 0.25, 0.1, "dddd", 8, None, 12, 43)
 
 
 def test_full_size_16384_windows(csim):
-    _window_check(csim, 16384, 16384, 0.05, 0.5, 0.25, 0.1, "dnnd", 6, None, 10, 44)
+    _window_check(csim, 16384, 16384, 0.05, 0.5, 0.25, 0.1, "dnnd", 8, None, 10, 44)
 
 
 def test_full_size_config5_32768_neumann(csim):
     """BASELINE configs[4]: 32768 x 32768, all-Neumann (2 x 8.6 GB on the device).  The reference is
     decomposition-invariant, so the single-GPU field is what the 4 x 2 run must give as well."""
-    _window_check(csim, 32768, 32768, 0.05, 0.5, 0.25, 0.1, "nnnn", 5, None, 8, 45)
+    _window_check(csim, 32768, 32768, 0.05, 0.5, 0.25, 0.1, "nnnn", 8, None, 8, 45)
 
 
 def test_physics_sanity_like_reference_integration_tests(csim):

@@ -4,7 +4,7 @@ mkdir -p gpurun_out
 timeout -k 10 1200 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; rc=$?; echo "pytest rc=$rc"
 tail -12 gpurun_out/pytest_gpu.log
 [ $rc -ne 0 ] && exit $rc
-timeout -k 10 600 python tools/sweep_variants.py --shape 16384x16384 4096x8192 8192x8192 --steps 25 --rounds 2 --variants 1 --ry 32 64 --pf 2 --fuse 2 3 4 --multistep 0 1 > gpurun_out/sweep_overlap.log 2>&1; echo "sweep rc=$?"
+timeout -k 10 600 python tools/sweep_variants.py --shape 16384x16384 4096x8192 8192x8192 --steps 25 --rounds 2 --variants 1 --ry 32 64 --pf 2 --fuse 4 5 6 --multistep 0 > gpurun_out/sweep_overlap.log 2>&1; echo "sweep rc=$?"
 grep "^{" gpurun_out/sweep_overlap.log | python3 -c "
 import sys, json
 for ln in sys.stdin:
