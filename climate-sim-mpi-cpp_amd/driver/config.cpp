@@ -12,7 +12,7 @@
 #include <sstream>
 #include <stdexcept>
 
-#include "climate/io.hpp"
+#include "climate/config.hpp"
 
 namespace {
 

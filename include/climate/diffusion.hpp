@@ -1,6 +1,3 @@
-// include/climate/diffusion.hpp — mirror of reference include/diffusion.hpp:4.
+// forwarding header: diffusion_step live in core.hpp (kept so the reference's include names still work)
 #pragma once
-#include "field.hpp"
-
-// FTCS 5-point diffusion of u into out + ring copy (reference src/diffusion.cpp:3-26), on the GPU.
-void diffusion_step(const Field& u, Field& out, double D, double dt);
+#include "core.hpp"

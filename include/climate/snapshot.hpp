@@ -10,10 +10,8 @@
 #include <string>
 #include <vector>
 
-#include "decomp.hpp"
-#include "field.hpp"
-#include "io.hpp"
-#include "mpi_shim.hpp"
+#include "config.hpp"
+#include "core.hpp"
 
 constexpr int NC_NOERR = 0;
 

@@ -10,10 +10,8 @@
 #include <stdexcept>
 #include <string>
 
-#include "boundary.hpp"
+#include "core.hpp"
 #include "csim.h"
-#include "decomp.hpp"
-#include "field.hpp"
 
 namespace climate {
 
