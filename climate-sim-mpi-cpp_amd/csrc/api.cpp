@@ -401,7 +401,6 @@ int csim_stepper_create(const csim_decomp* dec, double dx, double dy, const int 
         ok(hipMemset(s->buf[0], 0, s->bytes())) && ok(hipMemset(s->buf[1], 0, s->bytes())) &&
         ok(hipMalloc(reinterpret_cast<void**>(&s->scratch), sizeof(double) * 2 * REDUCE_BLOCKS)) &&
         ok(hipStreamCreateWithFlags(&s->s_comp, hipStreamNonBlocking)) &&
-        ok(hipStreamCreateWithFlags(&s->s_comm, hipStreamNonBlocking)) &&
         ok(hipEventCreateWithFlags(&s->ev_ready, hipEventDisableTiming)) &&
         ok(hipEventCreateWithFlags(&s->ev_edge, hipEventDisableTiming)) &&
         ok(hipEventCreateWithFlags(&s->ev_recv, hipEventDisableTiming));
@@ -446,9 +445,12 @@ int csim_stepper_create(const csim_decomp* dec, double dx, double dy, const int 
             ok(hipMemset(s->send2[d], 0, n)) && ok(hipMemset(s->recv2[d], 0, n));
     }
     if (e == hipSuccess) {
+        // the exchange and the frame tiles that feed it go on high-priority streams, so they are
+        // dispatched ahead of the bulk sweep that is hiding them
         int lo = 0, hi = 0;  // numerically lower = higher priority
         ok(hipDeviceGetStreamPriorityRange(&lo, &hi)) &&
-            ok(hipStreamCreateWithPriority(&s->s_frame, hipStreamNonBlocking, hi));
+            ok(hipStreamCreateWithPriority(&s->s_frame, hipStreamNonBlocking, hi)) &&
+            ok(hipStreamCreateWithPriority(&s->s_comm, hipStreamNonBlocking, hi));
     }
     if (e == hipSuccess) {
         ok(hipEventCreateWithFlags(&s->ev_edge2, hipEventDisableTiming)) &&
