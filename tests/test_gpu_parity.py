@@ -227,6 +227,37 @@ def test_seeded_random_vs_oracle_bit_exact(csim, case):
     assert np.array_equal(got, want)
 
 
+def test_subnormal_huge_and_nonfinite_values(csim):
+    """IEEE corner cases: subnormal and near-overflow magnitudes must come out bit-identical
+    (fp64 denormals are not flushed on gfx950), and NaN / Inf must spread to exactly the same
+    cells as on the CPU (NaN payloads are not compared)."""
+    nx, ny, steps = 256, 37, 7
+    rng = np.random.default_rng(77)
+    u0 = np.zeros((ny + 2, nx + 2))
+    u0[1:-1, 1:-1] = rng.standard_normal((ny, nx))
+    u0[1:-1, 1:65] *= 1e-310          # subnormal band
+    u0[1:-1, 65:129] *= 1e-300        # products underflow into the subnormal range
+    u0[1:-1, 129:193] *= 1e150        # huge but finite
+    bc = "dnpd"
+    for fuse in (0, 2, 4, 6):
+        want = u0.copy()
+        ora.run_single(want, 1.0, 1.0, 0.05, 0.5, -0.25, 0.1, ora.bc_codes(bc), steps)
+        got = run_gpu(csim, u0, 1.0, 1.0, 0.05, 0.5, -0.25, 0.1, csim.bc_codes(bc), steps, dict(fuse=fuse))
+        assert np.isfinite(want).all()
+        assert np.array_equal(got.view(np.int64), want.view(np.int64)), fuse
+    u1 = u0.copy()
+    u1[10, 40] = np.nan
+    u1[20, 200] = np.inf
+    u1[30, 100] = -np.inf
+    want = u1.copy()
+    ora.run_single(want, 1.0, 1.0, 0.05, 0.5, -0.25, 0.1, ora.bc_codes(bc), 4)
+    for fuse in (0, 4):
+        got = run_gpu(csim, u1, 1.0, 1.0, 0.05, 0.5, -0.25, 0.1, csim.bc_codes(bc), 4, dict(fuse=fuse))
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        ok = ~np.isnan(want)
+        assert np.array_equal(got[ok], want[ok])
+
+
 def test_fused_step_equals_copy_diffusion_advection(csim):
     """csim_fused_step == std::copy + diffusion_step + advection_step (main.cpp:104-107)."""
     rng = np.random.default_rng(3)
