@@ -168,7 +168,10 @@ def main():
         if world == 1 and os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
-                if tj.get("nx") == args.nx and tj.get("ny") == args.ny:
+                # PMC bytes were collected in separate rocprofv3 --pmc passes of this same command
+                # (tools/gpu_pmc.sh); only quoted when they belong to the kernel timed here
+                if (tj.get("nx") == args.nx and tj.get("ny") == args.ny
+                        and tj.get("steps_per_launch") == steps_per_launch):
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
