@@ -125,6 +125,19 @@ def main():
     st.init_gaussian(1.0, 0.05, 0.5, 0.5)
     dt = min(PHYS["dt"], csim.safe_dt(1.0, 1.0, PHYS["vx"], PHYS["vy"], PHYS["D"]))
 
+    def global_sum():
+        v = st.sum()
+        if world > 1:
+            t = torch.tensor([v], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            v = float(t.item())
+        return v
+
+    # FTCS diffusion + upwind advection conserve the total of u up to the flux through the
+    # physical edges (nil here: the hotspot stays far from them), so a halo exchange that lost
+    # or misplaced a face would show up as mass leaking at the tile seams through the centre
+    mass0 = global_sum()
+
     def barrier():
         st.sync()
         if world > 1:
@@ -149,6 +162,10 @@ def main():
     steps_per_launch = max(kinds, key=lambda t: t * kinds[t][1])
     kern_ms, launches = kinds[steps_per_launch]
     mn, mx = st.minmax()
+    mass1 = global_sum()
+    mass_drift = abs(mass1 - mass0) / abs(mass0)
+    if mass_drift > 1e-9 and rank == 0:
+        sys.stderr.write(f"[bench] WARNING: total mass drifted by {mass_drift:.3e} (halo exchange broken?)\n")
     st.close()
     if world > 1:
         km = torch.tensor([kern_ms], dtype=torch.float64)
@@ -195,6 +212,7 @@ def main():
                             f"halo overlap {'off' if args.no_overlap else 'on'}",
                 "hbm_gbs_whole_job": cells * args.steps * BYTES_PER_CELL / elapsed / 1e9,
                 "field_min_max_after_run": [mn, mx],
+                "relative_mass_drift": mass_drift,
             },
             "roofline": {
                 "bound": "hbm",
