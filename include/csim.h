@@ -136,16 +136,22 @@ int csim_stepper_faces_pack(csim_stepper* s, int depth, double* const host_send[
 int csim_stepper_faces_unpack(csim_stepper* s, int depth, const double* const host_recv[8]);
 /* reference src/halo.cpp:6-50  exchange_halos(u, dec, comm) on the current field */
 int csim_stepper_exchange_halos(csim_stepper* s);
-/* nsteps x { exchange_halos; apply_boundary; fused sweep; swap }, enqueued without host syncs */
+/* nsteps x { exchange_halos; apply_boundary; fused sweep; swap }, enqueued without host syncs;
+ * internally up to 6 steps share one pass over HBM, the last step of a call is always a single-step
+ * pass (so the ghost ring left in the field is the reference's) */
 int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy, int nsteps);
 int csim_stepper_sync(csim_stepper* s);
 int csim_stepper_minmax(csim_stepper* s, double out_min_max[2]);
 int csim_stepper_sum(csim_stepper* s, double* out);
-/* tuning / measurement knobs; unknown keys give CSIM_ERR_ARG.
- *   "variant" kernel family (0 auto, 1 dpp, 2 lds, 3 naive), "rows_per_chunk", "prefetch",
- *   "xcd_swizzle" (0/1), "fuse" (time steps per HBM pass: -1 auto, 0/1 off, 2..6), "multistep" (0 overlapped strips,
- *   1 edge-lane extras), "wide", "stagger", "overlap" (0/1: halo
- *   exchange on the second stream), "external_halo" (0/1), "profile" (0/1) */
+/* tuning / measurement knobs; unknown keys give CSIM_ERR_ARG.  Results never depend on them.
+ *   "fuse"           time steps per HBM pass: -1 auto (deepest the decomposition allows), 0/1 off, 2..6
+ *   "multistep"      multi-step kernel family: 0 overlapped strips (default), 1 edge-lane extras (<= 4 steps)
+ *   "variant"        single-step kernel family: 0 auto, 1 dpp, 2 lds, 3 naive
+ *   "rows_per_chunk" rows one wavefront marches per launch (0 auto), "prefetch" (single-step kernel)
+ *   "xcd_swizzle"    0/1 XCD-aware block->tile map; "wide", "stagger": measured alternatives, off
+ *   "overlap"        0/1 halo exchange on the comm stream concurrently with the sweep
+ *   "external_halo"  0/1 the caller carries the faces (csim_stepper_halo_* / _faces_*)
+ *   "profile"        0/1 HIP events around every sweep launch (csim_stepper_kernel_time) */
 int csim_stepper_set_option(csim_stepper* s, const char* key, long value);
 /* with option "profile"=1: HIP-event time (on the compute stream) and count of the sweep
  * launches since the last reset, per kernel kind: steps_per_launch = 1 selects the single-step
