@@ -1,11 +1,18 @@
 // kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the advection–diffusion hot path.
 //
-// The path is HBM-bandwidth-bound (16 algorithmic bytes and ~15 fp64 flops per cell update),
-// so there is no MFMA here; the rules that matter are 16-byte-per-lane coalesced row accesses
-// on 128-byte-aligned rows, one HBM read and one HBM write per cell (vertical reuse in
-// registers while a wavefront marches up its column strip, horizontal reuse through
-// cross-lane DPP moves or an LDS-staged row), enough row loads in flight per wavefront to
-// cover HBM latency, and an XCD-aware block->tile map so strip/chunk neighbours share an L2.
+// The path is HBM-bandwidth-bound by nature (16 algorithmic bytes and ~14 fp64 flops per cell
+// update), so there is no MFMA here.  What matters:
+//   * 16-byte-per-lane coalesced row accesses on 128-byte-aligned rows, each cell read once and
+//     written once per PASS: vertical reuse in registers while a wavefront marches up its column
+//     strip, horizontal reuse through cross-lane DPP moves (an LDS-staged variant is kept for
+//     comparison), row loads kept in flight to cover HBM latency, XCD-aware block->tile map;
+//   * temporal blocking: up to six time levels stay in registers per pass (k_sweepO_dpp, the
+//     default), which divides the HBM traffic per step by six and leaves the kernel bound by the
+//     reference's own fp64 add/mul stream.
+// Kernel families, in file order: k_sweep_dpp (1 step/pass), k_sweep2_dpp and k_sweepT_dpp
+// (2 and 3-4 steps/pass, edge-lane extras), k_sweepO_dpp (2-6 steps/pass, overlapped strips,
+// DEFAULT), k_sweepTw_dpp (wide strips), k_sweep_lds, k_sweep_naive, then the small kernels
+// (ghost fill / extend, edge and face packing, reference-granularity operators, reductions).
 //
 // Arithmetic follows the reference's association order exactly (reference
 // src/diffusion.cpp:9-16, src/advection.cpp:13-33) and this file is compiled with
