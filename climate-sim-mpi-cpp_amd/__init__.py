@@ -123,6 +123,7 @@ def lib() -> C.CDLL:
         "csim_stepper_exchange_halos": (i, [vp]),
         "csim_stepper_halo_pack": (i, [vp, C.POINTER(dp)]),
         "csim_stepper_halo_unpack": (i, [vp, C.POINTER(dp)]),
+        "csim_stepper_fuse_limit": (i, [vp, ip]),
         "csim_stepper_faces_neighbors": (i, [vp, i, ip, ip]),
         "csim_stepper_faces_pack": (i, [vp, i, C.POINTER(dp)]),
         "csim_stepper_faces_unpack": (i, [vp, i, C.POINTER(dp)]),
@@ -326,6 +327,11 @@ class Stepper:
         out = np.empty((self.ny, self.nx))
         _ck(lib().csim_stepper_download_interior(self._h, _dp(out)))
         return out
+
+    def fuse_limit(self) -> int:
+        d = C.c_int(0)
+        _ck(lib().csim_stepper_fuse_limit(self._h, C.byref(d)))
+        return d.value
 
     def faces_neighbors(self, depth):
         peers, lens = (C.c_int * 8)(), (C.c_int * 8)()

@@ -662,6 +662,18 @@ static bool depth_ok(const csim_stepper* s, int depth) {
     return depth >= 2 && depth <= MAX_FUSE && depth <= s->nx && depth <= s->ny;
 }
 
+// deepest fused pass this stepper can run (1 = single steps only); identical on every rank of a
+// decomposition, so external-transport callers can schedule their passes the way run() does
+int csim_stepper_fuse_limit(const csim_stepper* s, int* depth) {
+    CSIM_REQUIRE(s && depth, "null argument");
+    int d = std::min(s->fuse < 0 ? MAX_FUSE : s->fuse, s->fuse_cap);
+    if (s->cfg.multistep == MS_EXTRAS) d = std::min(d, 4);
+    const bool dpp_family = s->cfg.variant == VAR_AUTO || s->cfg.variant == VAR_DPP;
+    const bool ok = d >= 2 && dpp_family && (s->cfg.multistep == MS_OVERLAP || s->widths128);
+    *depth = ok ? d : 1;
+    return CSIM_OK;
+}
+
 int csim_stepper_faces_neighbors(const csim_stepper* s, int depth, int peers[8], int lengths[8]) {
     CSIM_REQUIRE(s && peers && lengths, "null argument");
     CSIM_REQUIRE(depth_ok(s, depth), "face depth must be 2..6 and fit the tile");

@@ -131,6 +131,7 @@ int csim_stepper_halo_unpack(csim_stepper* s, const double* const host_recv[4]);
  * per direction (depth*(ny+2), depth*(nx+2), depth*depth).  The face packed for direction d must be
  * delivered to peers[d], which unpacks it as coming from the opposite direction (d ^ 1 for
  * sides, 11 - d for corners). */
+int csim_stepper_fuse_limit(const csim_stepper* s, int* depth); /* deepest pass available (1 = none) */
 int csim_stepper_faces_neighbors(const csim_stepper* s, int depth, int peers[8], int lengths[8]);
 int csim_stepper_faces_pack(csim_stepper* s, int depth, double* const host_send[8]);
 int csim_stepper_faces_unpack(csim_stepper* s, int depth, const double* const host_recv[8]);

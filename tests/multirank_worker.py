@@ -122,8 +122,9 @@ def main():
         st = csim.Stepper(dec, m["dx"], m["dy"], bc)
         st.set_option("external_halo", 1)
         st.upload(u)
+        depth = min(depth, st.fuse_limit())  # tiny tiles cap the depth (same value on every rank)
         remaining = m["steps"]
-        while remaining >= 3:
+        while remaining >= 3 and depth >= 2:
             t = min(depth, remaining - 1)
             peers, _ = st.faces_neighbors(t)
             st.faces_unpack(t, exchange8(st.faces_pack(t), peers))
