@@ -119,6 +119,8 @@ def lib() -> C.CDLL:
         "csim_stepper_upload": (i, [vp, dp]),
         "csim_stepper_download": (i, [vp, dp]),
         "csim_stepper_download_interior": (i, [vp, dp]),
+        "csim_stepper_snapshot_begin": (i, [vp]),
+        "csim_stepper_snapshot_wait": (i, [vp, C.POINTER(dp)]),
         "csim_stepper_init_gaussian": (i, [vp, d, d, d, d]),
         "csim_stepper_exchange_halos": (i, [vp]),
         "csim_stepper_halo_pack": (i, [vp, C.POINTER(dp)]),
@@ -350,6 +352,15 @@ class Stepper:
         keep = [np.ascontiguousarray(b, dtype=np.float64) if b is not None else None for b in faces]
         arr = (C.POINTER(C.c_double) * 8)(*[_dp(b) if b is not None else None for b in keep])
         _ck(lib().csim_stepper_faces_unpack(self._h, depth, arr))
+
+    def snapshot_begin(self):
+        _ck(lib().csim_stepper_snapshot_begin(self._h))
+
+    def snapshot_wait(self) -> np.ndarray:
+        """copy of the interior captured by the last snapshot_begin()"""
+        ptr = C.POINTER(C.c_double)()
+        _ck(lib().csim_stepper_snapshot_wait(self._h, C.byref(ptr)))
+        return np.ctypeslib.as_array(ptr, shape=(self.ny, self.nx)).copy()
 
     def init_gaussian(self, A=1.0, sigma_frac=0.05, xc_frac=0.5, yc_frac=0.5):
         _ck(lib().csim_stepper_init_gaussian(self._h, A, sigma_frac, xc_frac, yc_frac))

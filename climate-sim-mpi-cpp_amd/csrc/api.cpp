@@ -136,6 +136,12 @@ struct csim_stepper {
     double* send2[8]{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double* recv2[8]{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_edge2 = nullptr, ev_recv2 = nullptr;
+    // asynchronous snapshot of the interior (device staging copy + pinned host buffer + I/O stream)
+    double* snap_d = nullptr;
+    double* snap_h = nullptr;
+    hipStream_t s_io = nullptr;
+    hipEvent_t ev_snap_src = nullptr, ev_snap_copied = nullptr;
+    bool snap_pending = false;
     int fuse_cap = 1;     // deepest pass every rank of the decomposition can run (same on all ranks)
     bool widths128 = false;  // every tile width of the decomposition is a multiple of 128
     int faces_depth = 0;  // recv2[] holds the neighbours' faces of `cur` of this depth (0 = none)
@@ -474,6 +480,12 @@ int csim_stepper_destroy(csim_stepper* s) {
     if (s->s_comp) (void)hipStreamSynchronize(s->s_comp);
     if (s->s_comm) (void)hipStreamSynchronize(s->s_comm);
     if (s->s_frame) (void)hipStreamSynchronize(s->s_frame);
+    if (s->s_io) (void)hipStreamSynchronize(s->s_io);
+    if (s->snap_d) (void)hipFree(s->snap_d);
+    if (s->snap_h) (void)hipHostFree(s->snap_h);
+    if (s->ev_snap_src) (void)hipEventDestroy(s->ev_snap_src);
+    if (s->ev_snap_copied) (void)hipEventDestroy(s->ev_snap_copied);
+    if (s->s_io) (void)hipStreamDestroy(s->s_io);
     if (s->comm) (void)ncclCommDestroy(s->comm);
     for (hipEvent_t ev : s->ev_pool) (void)hipEventDestroy(ev);
     for (int k = 0; k < 4; ++k) {
@@ -545,6 +557,45 @@ int csim_stepper_download_interior(csim_stepper* s, double* host) {
     CSIM_REQUIRE(s && host, "null argument");
     CSIM_HIP(hipStreamSynchronize(s->s_comp));
     return download_interior_2d(s->cur, s->nx, s->ny, s->pitch, host);
+}
+
+// Snapshot without stalling the time loop (the reference packs and writes the interior inside the
+// step loop, src/io.cpp:402-424 called from src/main.cpp:96-99).  _begin enqueues a device-side
+// copy of the current interior (the ping-pong buffers are free to move on after ~1 ms) followed
+// by an asynchronous D2H into a pinned buffer on a third stream, and returns at once; the caller
+// keeps enqueuing steps and calls _wait when it wants the data (pointer valid until the next
+// _begin).  Layout: ny_local x nx_local, row-major — what write_field_netcdf packs.
+int csim_stepper_snapshot_begin(csim_stepper* s) {
+    CSIM_REQUIRE(s, "null stepper");
+    const size_t bytes = sizeof(double) * static_cast<size_t>(s->nx) * s->ny;
+    if (!s->s_io) {
+        CSIM_HIP(hipStreamCreateWithFlags(&s->s_io, hipStreamNonBlocking));
+        CSIM_HIP(hipEventCreateWithFlags(&s->ev_snap_src, hipEventDisableTiming));
+        CSIM_HIP(hipEventCreateWithFlags(&s->ev_snap_copied, hipEventDisableTiming));
+        CSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s->snap_d), bytes));
+        CSIM_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->snap_h), bytes, hipHostMallocDefault));
+    }
+    if (s->snap_pending) CSIM_HIP(hipStreamSynchronize(s->s_io));  // previous snapshot still in flight
+    CSIM_HIP(hipEventRecord(s->ev_snap_src, s->s_comp));
+    CSIM_HIP(hipStreamWaitEvent(s->s_io, s->ev_snap_src, 0));
+    CSIM_HIP(hipMemcpy2DAsync(s->snap_d, sizeof(double) * s->nx, s->cur + s->pitch + LPAD,
+                              sizeof(double) * s->pitch, sizeof(double) * s->nx, s->ny,
+                              hipMemcpyDeviceToDevice, s->s_io));
+    CSIM_HIP(hipEventRecord(s->ev_snap_copied, s->s_io));
+    // the sweeps may overwrite the source buffer only after the staging copy has read it
+    CSIM_HIP(hipStreamWaitEvent(s->s_comp, s->ev_snap_copied, 0));
+    CSIM_HIP(hipMemcpyAsync(s->snap_h, s->snap_d, bytes, hipMemcpyDeviceToHost, s->s_io));
+    s->snap_pending = true;
+    return CSIM_OK;
+}
+
+int csim_stepper_snapshot_wait(csim_stepper* s, const double** host_interior) {
+    CSIM_REQUIRE(s && host_interior, "null argument");
+    if (!s->snap_pending) return fail(CSIM_ERR_STATE, "no snapshot in flight: csim_stepper_snapshot_begin first");
+    CSIM_HIP(hipStreamSynchronize(s->s_io));
+    s->snap_pending = false;
+    *host_interior = s->snap_h;
+    return CSIM_OK;
 }
 
 int csim_stepper_init_gaussian(csim_stepper* s, double A, double sigma_frac, double xc_frac,

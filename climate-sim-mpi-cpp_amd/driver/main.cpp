@@ -161,9 +161,6 @@ int main(int argc, char** argv) {
         open_netcdf_parallel("outputs/snapshots.nc", dec, cfg, MPI_COMM_WORLD, ncid, varid);
     }
 
-    std::vector<double> interior;
-    if (!no_output) interior.resize(static_cast<size_t>(dec.nx_local) * dec.ny_local);
-
     st.sync();
     const double t0 = now_s();
     double sum_step = 0.0;
@@ -171,10 +168,10 @@ int main(int argc, char** argv) {
     int n = 0;
     while (n < cfg.steps) {
         const double ts = now_s();
-        if (!no_output && n % cfg.out_every == 0) {
-            st.download_interior(interior.data());
-            write_interior_netcdf(ncid, varid, interior.data(), dec, time_index++);
-        }
+        // snapshot of the state BEFORE step n: captured on the device now, copied to the host and
+        // written to the file while the GPU is already running the next steps
+        const bool snap = !no_output && n % cfg.out_every == 0;
+        if (snap) st.snapshot_begin();
         int k = no_output ? cfg.steps - n : std::min(cfg.out_every - n % cfg.out_every, cfg.steps - n);
 #ifdef CSIM_WITH_MPI
         if (world_size > 1 && halo_mpi) {  // reference-style MPI faces around single GPU steps
@@ -203,7 +200,8 @@ int main(int argc, char** argv) {
             climate::check(csim_stepper_halo_unpack(st.handle(), rp));
         }
 #endif
-        st.run(cfg.D, cfg.dt, cfg.vx, cfg.vy, k);
+        st.run(cfg.D, cfg.dt, cfg.vx, cfg.vy, k);  // enqueued, not waited for
+        if (snap) write_interior_netcdf(ncid, varid, st.snapshot_wait(), dec, time_index++);
         st.sync();
         n += k;
         sum_step += now_s() - ts;

@@ -52,6 +52,14 @@ class Stepper {
     void upload(const Field& u) { check(csim_stepper_upload(h_, u.data.data())); }
     void download(Field& u) { check(csim_stepper_download(h_, u.data.data())); }
     void download_interior(double* ny_by_nx) { check(csim_stepper_download_interior(h_, ny_by_nx)); }
+    // asynchronous snapshot: begin() returns at once, the loop keeps stepping, wait() hands out the
+    // ny_local x nx_local interior as of begin() (valid until the next begin())
+    void snapshot_begin() { check(csim_stepper_snapshot_begin(h_)); }
+    const double* snapshot_wait() {
+        const double* p = nullptr;
+        check(csim_stepper_snapshot_wait(h_, &p));
+        return p;
+    }
     void init_gaussian(double A, double sigma_frac, double xc_frac, double yc_frac) {
         check(csim_stepper_init_gaussian(h_, A, sigma_frac, xc_frac, yc_frac));
     }

@@ -115,6 +115,13 @@ int csim_stepper_comm_init(csim_stepper* s, const void* id, size_t nbytes);
 int csim_stepper_upload(csim_stepper* s, const double* host_with_ghosts);   /* local tile */
 int csim_stepper_download(csim_stepper* s, double* host_with_ghosts);
 int csim_stepper_download_interior(csim_stepper* s, double* host_ny_by_nx);
+/* snapshot without stalling the loop (reference src/io.cpp:402-424 packs + writes inside the step
+ * loop, src/main.cpp:96-99): _begin enqueues a device-side copy of the current interior and an
+ * asynchronous D2H into a pinned buffer on a third stream and returns at once; keep calling
+ * csim_stepper_run, then _wait for the ny_local x nx_local row-major data (valid until the next
+ * _begin). */
+int csim_stepper_snapshot_begin(csim_stepper* s);
+int csim_stepper_snapshot_wait(csim_stepper* s, const double** host_interior);
 /* gaussian hotspot written on the device (reference src/init.cpp:12-33) */
 int csim_stepper_init_gaussian(csim_stepper* s, double A, double sigma_frac, double xc_frac,
                                double yc_frac);

@@ -279,6 +279,33 @@ def test_fused_step_equals_copy_diffusion_advection(csim):
     assert np.array_equal(a.download(), tmp)
 
 
+def test_async_snapshot_captures_the_state_at_begin(csim):
+    """csim_stepper_snapshot_begin/_wait: the loop keeps stepping while the snapshot travels; the
+    data handed out is the interior as of begin() (reference write_field_netcdf semantics)."""
+    nx, ny = 1536, 700
+    rng = np.random.default_rng(21)
+    u0 = np.zeros((ny + 2, nx + 2))
+    u0[1:-1, 1:-1] = rng.random((ny, nx))
+    st = csim.Stepper.single(nx, ny, 1.0, 1.0, csim.bc_codes("dnnd"))
+    st.upload(u0)
+    st.run(0.05, 0.1, 0.5, 0.25, 7)
+    at7 = st.download_interior()
+    st.snapshot_begin()
+    st.run(0.05, 0.1, 0.5, 0.25, 20)   # enqueued right behind the snapshot
+    snap = st.snapshot_wait()
+    assert np.array_equal(snap, at7)
+    st.snapshot_begin()
+    st.snapshot_begin()                # a second begin waits for the first one
+    at27 = st.snapshot_wait()
+    assert np.array_equal(at27, st.download_interior())
+    with pytest.raises(csim.CsimError):
+        st.snapshot_wait()             # nothing in flight any more
+    st.close()
+    want = u0.copy()
+    ora.run_single(want, 1.0, 1.0, 0.05, 0.5, 0.25, 0.1, ora.bc_codes("dnnd"), 27)
+    assert np.array_equal(at27, want[1:-1, 1:-1])
+
+
 def test_reductions(csim):
     rng = np.random.default_rng(8)
     nx, ny = 1234, 567
