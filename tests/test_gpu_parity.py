@@ -397,6 +397,37 @@ def test_full_size_config5_32768_neumann(csim):
     _window_check(csim, 32768, 32768, 0.05, 0.5, 0.25, 0.1, "nnnn", 8, None, 8, 45)
 
 
+def test_long_run_all_schedules_agree_bitwise(csim):
+    """1500 steps at 2048^2: six-, four-, two-step passes, single steps and the LDS kernel must
+    leave bit-identical fields (same arithmetic per cell, whatever the schedule), mass conserved
+    (Neumann walls), maximum principle respected."""
+    nx = ny = 2048
+    steps = 1500
+    outs = {}
+    sums = {}
+    for name, opts in [("fuse6", dict(fuse=6)), ("fuse4", dict(fuse=4)), ("fuse2", dict(fuse=2)),
+                       ("fuse0", dict(fuse=0)), ("lds", dict(fuse=0, variant=2)),
+                       ("extras4", dict(fuse=4, multistep=1))]:
+        st = csim.Stepper.single(nx, ny, 1.0, 1.0, csim.bc_codes("nnnn"))
+        for k, v in opts.items():
+            st.set_option(k, v)
+        st.init_gaussian(1.0, 0.05, 0.5, 0.5)
+        if name == "fuse6":
+            mass0, (mn0, mx0) = st.sum(), st.minmax()
+        # uneven call pattern on purpose
+        st.run(0.2, 0.1, 0.5, -0.25, 1)
+        st.run(0.2, 0.1, 0.5, -0.25, 998)
+        st.run(0.2, 0.1, 0.5, -0.25, steps - 999)
+        outs[name] = st.download()
+        sums[name] = (st.sum(), st.minmax())
+        st.close()
+    for name in outs:
+        assert np.array_equal(outs[name], outs["fuse0"]), name
+    mass1, (mn1, mx1) = sums["fuse6"]
+    assert abs(mass1 - mass0) <= 1e-12 * abs(mass0)
+    assert mn1 >= mn0 - 1e-15 and mx1 < mx0
+
+
 def test_physics_sanity_like_reference_integration_tests(csim):
     """reference tests/simulation/integration/integration_{diffusion,advection}.cpp: the peak of
     a diffusing hotspot decreases and stays >= 0; an advected hotspot's centre of mass moves by
