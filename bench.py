@@ -25,7 +25,6 @@ import argparse
 import json
 import os
 import re
-import subprocess
 import sys
 import time
 
@@ -41,7 +40,7 @@ PHYS = dict(D=0.05, vx=0.5, vy=0.25, dt=0.1)
 BC = "dddd"
 
 
-def cpu_baseline(cores: int, budget_s: float = 25.0):
+def cpu_baseline(cores: int):
     """Reference CPU path on the host cores, bounded sample of the same workload."""
     from oracle import cpu_oracle as ora
     nx = ny = int(os.environ.get("CSIM_BENCH_CPU_N", NX))

@@ -145,9 +145,6 @@ def lib() -> C.CDLL:
     return L
 
 
-EXPORTS = None  # filled lazily by declared_symbols()
-
-
 def declared_symbols():
     """Every function name declared in include/csim.h (parsed from the header text)."""
     import re

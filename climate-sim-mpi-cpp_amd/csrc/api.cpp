@@ -14,7 +14,6 @@
 namespace csim {
 
 static thread_local std::string g_err;
-void set_error(const std::string& msg) { g_err = msg; }
 int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;

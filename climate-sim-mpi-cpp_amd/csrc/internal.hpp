@@ -33,7 +33,6 @@ constexpr int WAVE_COLS = 128;  // columns one wavefront covers per row (64 lane
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 inline int pitch_for(int nx) { return LPAD + round_up(nx + 1, WAVE_COLS) + WAVE_COLS; }
 
-void set_error(const std::string& msg);
 int fail(int code, const std::string& msg);
 
 #define CSIM_HIP(expr)                                                                       \
