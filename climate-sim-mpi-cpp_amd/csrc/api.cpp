@@ -881,8 +881,7 @@ static int pass_fused(csim_stepper* s, const Phys& p, int T, int next_T) {
         }
         CSIM_HIP(launch_halo2_unpack(s->cur, s->nx, s->ny, s->pitch, T, s->recv2, s->s_comp));
     }
-    CSIM_HIP(launch_ghost_fill(s->cur, s->nxt, s->nx, s->ny, s->pitch, g, s->s_comp));
-    if (s->multi) CSIM_HIP(launch_ghost_extend(s->cur, s->nx, s->ny, s->pitch, T, g, s->s_comp));
+    CSIM_HIP(launch_ghost_fill(s->cur, s->nxt, s->nx, s->ny, s->pitch, g, s->s_comp, s->multi ? T : 0));
     int rc = prof_begin(s, T);
     if (rc) return rc;
     if (rccl && s->overlap && next_T >= 2) {

@@ -109,12 +109,11 @@ struct GhostArgs {
     const double* recv[4];  // per side: staged halo from the neighbour (nullptr on physical sides)
 };
 // boundary fill (+ unpack of received halos) written to `a` and, when b != nullptr, to `b` too
+// ext_depth > 0 additionally continues each physical Dirichlet/Neumann edge over that many halo
+// cells of an adjacent neighbour side (needed by fused passes across ranks; reads halo cells a
+// preceding launch_halo2_unpack wrote)
 hipError_t launch_ghost_fill(double* a, double* b, int nx, int ny, int pitch, const GhostArgs& g,
-                             hipStream_t st);
-// the boundary rule of a physical side continued over the `depth` halo cells of an adjacent
-// neighbour side (needed by fused passes deeper than the plain ghost fill reaches)
-hipError_t launch_ghost_extend(double* f, int nx, int ny, int pitch, int depth, const GhostArgs& g,
-                               hipStream_t st);
+                             hipStream_t st, int ext_depth = 0);
 // updated values of the four edge lines of the NEXT field, computed from `in` and written
 // straight into the send staging buffers (nullptr = side not needed)
 hipError_t launch_edge_pack(const double* in, int nx, int ny, int pitch, const Phys& p,

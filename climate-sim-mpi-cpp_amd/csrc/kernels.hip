@@ -1038,10 +1038,37 @@ struct GhostDev {
     int phys[4];
     double value;
     const double* recv[4];
+    int ext_depth;  // > 0: also continue physical edges over that many halo cells (see ghost_extend_cell)
 };
 
 __device__ __forceinline__ size_t at(int i, int j, int pitch) {
     return static_cast<size_t>(j) * pitch + (LPAD - 1) + i;
+}
+
+// apply_boundary on the HALO part of a physical side: where a Dirichlet/Neumann edge meets a
+// neighbour side, the ghost line continues over the H halo cells that came from that neighbour
+// (globally, they are the neighbour's own ghost cells of the same physical edge).  t = 8
+// segments x H cells.  Inputs are halo cells written by the preceding k_halo2_unpack launch.
+__device__ __forceinline__ void ghost_extend_cell(double* __restrict__ f, int nx, int ny, int pitch, int H,
+                                                  const int bc[4], const int phys[4], double value, int t) {
+    const int seg = t / H, k = t % H;
+    if (seg >= 8) return;
+    auto at2 = [&](int i, int j) -> double& { return f[static_cast<ptrdiff_t>(j) * pitch + (LPAD - 1) + i]; };
+    // segments 0..3: physical bottom/top row over the left/right halo columns
+    // segments 4..7: physical left/right column over the bottom/top halo rows
+    if (seg < 4) {
+        const int row_side = (seg & 1) ? CSIM_TOP : CSIM_BOTTOM, col_side = (seg & 2) ? CSIM_RIGHT : CSIM_LEFT;
+        if (!phys[row_side] || phys[col_side] || bc[row_side] == CSIM_BC_PERIODIC) return;
+        const int i = col_side == CSIM_LEFT ? -k : nx + 1 + k;
+        const int jg = row_side == CSIM_BOTTOM ? 0 : ny + 1, ja = row_side == CSIM_BOTTOM ? 1 : ny;
+        at2(i, jg) = bc[row_side] == CSIM_BC_DIRICHLET ? value : at2(i, ja);
+    } else {
+        const int col_side = (seg & 1) ? CSIM_RIGHT : CSIM_LEFT, row_side = (seg & 2) ? CSIM_TOP : CSIM_BOTTOM;
+        if (!phys[col_side] || phys[row_side] || bc[col_side] == CSIM_BC_PERIODIC) return;
+        const int j = row_side == CSIM_BOTTOM ? -k : ny + 1 + k;
+        const int ig = col_side == CSIM_LEFT ? 0 : nx + 1, ia = col_side == CSIM_LEFT ? 1 : nx;
+        at2(ig, j) = bc[col_side] == CSIM_BC_DIRICHLET ? value : at2(ia, j);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_ghost_fill(double* __restrict__ a, double* __restrict__ b,
@@ -1082,6 +1109,11 @@ __global__ __launch_bounds__(256) void k_ghost_fill(double* __restrict__ a, doub
         }
     }
     const int tc = nx > ny ? nx : ny;
+    if (g.ext_depth > 0 && t > tc && t <= tc + 8 * g.ext_depth) {
+        // (same values as the corner thread wherever the two overlap, so the order is immaterial)
+        ghost_extend_cell(a, nx, ny, pitch, g.ext_depth, g.bc, g.phys, g.value, t - tc - 1);
+        return;
+    }
     if (t == tc) {  // the four corners
         for (int cs = CSIM_LEFT; cs <= CSIM_RIGHT; ++cs) {
             const int ig = cs == CSIM_LEFT ? 0 : nx + 1;
@@ -1221,37 +1253,6 @@ __global__ __launch_bounds__(256) void k_halo2_unpack(double* __restrict__ f, in
         if (r.p[5]) st(nx + 1 + c, 1 - H + q, r.p[5][t]);
         if (r.p[6]) st(1 - H + c, ny + 1 + q, r.p[6][t]);
         if (r.p[7]) st(nx + 1 + c, ny + 1 + q, r.p[7][t]);
-    }
-}
-
-// apply_boundary on the HALO part of a physical side: where a Dirichlet/Neumann edge meets a
-// neighbour side, the ghost line continues over the H halo cells that came from that neighbour
-// (globally, they are the neighbour's own ghost cells of the same physical edge).
-struct GhostExt {
-    int bc[4];
-    int phys[4];
-    double value;
-};
-__global__ __launch_bounds__(64) void k_ghost_extend(double* __restrict__ f, int nx, int ny, int pitch,
-                                                     int H, GhostExt g) {
-    const int t = threadIdx.x;  // 8 segments x H cells
-    const int seg = t / H, k = t % H;
-    if (seg >= 8) return;
-    auto at2 = [&](int i, int j) -> double& { return f[static_cast<ptrdiff_t>(j) * pitch + (LPAD - 1) + i]; };
-    // segments 0..3: physical bottom/top row over the left/right halo columns
-    // segments 4..7: physical left/right column over the bottom/top halo rows
-    if (seg < 4) {
-        const int row_side = (seg & 1) ? CSIM_TOP : CSIM_BOTTOM, col_side = (seg & 2) ? CSIM_RIGHT : CSIM_LEFT;
-        if (!g.phys[row_side] || g.phys[col_side] || g.bc[row_side] == CSIM_BC_PERIODIC) return;
-        const int i = col_side == CSIM_LEFT ? -k : nx + 1 + k;
-        const int jg = row_side == CSIM_BOTTOM ? 0 : ny + 1, ja = row_side == CSIM_BOTTOM ? 1 : ny;
-        at2(i, jg) = g.bc[row_side] == CSIM_BC_DIRICHLET ? g.value : at2(i, ja);
-    } else {
-        const int col_side = (seg & 1) ? CSIM_RIGHT : CSIM_LEFT, row_side = (seg & 2) ? CSIM_TOP : CSIM_BOTTOM;
-        if (!g.phys[col_side] || g.phys[row_side] || g.bc[col_side] == CSIM_BC_PERIODIC) return;
-        const int j = row_side == CSIM_BOTTOM ? -k : ny + 1 + k;
-        const int ig = col_side == CSIM_LEFT ? 0 : nx + 1, ia = col_side == CSIM_LEFT ? 1 : nx;
-        at2(ig, j) = g.bc[col_side] == CSIM_BC_DIRICHLET ? g.value : at2(ia, j);
     }
 }
 
@@ -1609,15 +1610,16 @@ hipError_t launch_fill(double* f, int nx, int ny, int pitch, double v, hipStream
 }
 
 hipError_t launch_ghost_fill(double* a, double* b, int nx, int ny, int pitch, const GhostArgs& g,
-                             hipStream_t st) {
+                             hipStream_t st, int ext_depth) {
     GhostDev d;
+    d.ext_depth = ext_depth;
     for (int s = 0; s < 4; ++s) {
         d.bc[s] = g.bc[s];
         d.phys[s] = g.phys[s];
         d.recv[s] = g.recv[s];
     }
     d.value = g.value;
-    const int n = (nx > ny ? nx : ny) + 1;
+    const int n = (nx > ny ? nx : ny) + 1 + 8 * ext_depth;
     hipLaunchKernelGGL(k_ghost_fill, dim3(cdiv(n, 256)), dim3(256), 0, st, a, b, nx, ny, pitch, d);
     return hipGetLastError();
 }
@@ -1639,18 +1641,6 @@ hipError_t launch_pack(const double* in, int nx, int ny, int pitch, double* cons
     const int n = nx > ny ? nx : ny;
     hipLaunchKernelGGL(k_pack, dim3(cdiv(n, 256)), dim3(256), 0, st, in, nx, ny, pitch, send[0],
                        send[1], send[2], send[3]);
-    return hipGetLastError();
-}
-
-hipError_t launch_ghost_extend(double* f, int nx, int ny, int pitch, int depth, const GhostArgs& g,
-                               hipStream_t st) {
-    GhostExt e;
-    for (int s = 0; s < 4; ++s) {
-        e.bc[s] = g.bc[s];
-        e.phys[s] = g.phys[s];
-    }
-    e.value = g.value;
-    hipLaunchKernelGGL(k_ghost_extend, dim3(1), dim3(64), 0, st, f, nx, ny, pitch, depth, e);
     return hipGetLastError();
 }
 
