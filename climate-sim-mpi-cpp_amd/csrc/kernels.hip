@@ -567,6 +567,28 @@ __device__ __forceinline__ double shift_from_next(double src) {  // lane i <- la
     return __hiloint2double(hi, lo);
 }
 
+#ifdef CSIM_TRACE
+// tools/wavetrace.hip only: start/end time (100 MHz wall clock) and placement of every wavefront
+__device__ unsigned long long* g_wave_trace = nullptr;
+struct WaveTrace {
+    int slot, lane;
+    unsigned long long t0;
+    __device__ WaveTrace(int s, int l) : slot(s), lane(l), t0(wall_clock64()) {}
+    __device__ ~WaveTrace() {
+        if (lane == 0 && g_wave_trace) {
+            g_wave_trace[3 * slot] = t0;
+            g_wave_trace[3 * slot + 1] = wall_clock64();
+            g_wave_trace[3 * slot + 2] = (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg(63508)) << 32) |
+                                         static_cast<unsigned>(__builtin_amdgcn_s_getreg(63492));
+        }
+    }
+};
+#endif
+
+// An empty volatile asm cannot be speculated, so the block it sits in stays a real (wave-uniform)
+// branch instead of being if-converted into per-lane selects on the hot path.
+__device__ __forceinline__ void keep_branch() { asm volatile(""); }
+
 template <int T>
 struct OverlapGeom {
     static constexpr int TP = 2 * ((T + 1) / 2);       // T rounded up to even
@@ -586,6 +608,10 @@ __device__ __forceinline__ void sweepO_march(const double* __restrict__ in, doub
     // output lanes: local columns [TP, TP + STRIDE), clipped to the interior
     const bool out_lane = 2 * lane >= TP && 2 * lane < TP + STRIDE && gx < nx;
     const int nvalid = nx - gx;
+    // lanes that hold a ghost column of a physical edge (EDGE bodies only)
+    const bool ghost_ly = kl != 3 && gy == -1;
+    const bool ghost_rx = kr != 3 && gx == nx, ghost_ry = kr != 3 && gy == nx;
+    const bool ghost_cols = kl != 3 || kr != 3;  // wave-uniform
 
     auto load = [&](int j) {
         return *reinterpret_cast<const double2*>(in + static_cast<ptrdiff_t>(j) * pitch + xoff);
@@ -594,14 +620,16 @@ __device__ __forceinline__ void sweepO_march(const double* __restrict__ in, doub
     const int r_first = jb - (T - 1);
     const int niter = (je - jb + 1) + 2 * (T - 1);
     const int last_row = r_first + niter;
+    // Every load below is unconditional (row index clamped to the last row the chunk needs) and
+    // the march runs whole groups of six iterations without a per-iteration exit test: a memory
+    // operation that may or may not have been issued makes the compiler wait for ALL of them
+    // (s_waitcnt vmcnt(0)) at the top of every iteration, which would serialise the row prefetch.
+    // The <= 5 surplus iterations of a chunk whose niter is not a multiple of six compute rows
+    // beyond je that are never stored (the host picks ry so that only a ragged last chunk has any).
     double2 L0[6];
     double2 L[T][3];
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        L0[q] = make_double2(0.0, 0.0);
-        const int row = r_first - 1 + q;
-        if (row <= last_row) L0[q] = load(row);
-    }
+    for (int q = 0; q < 6; ++q) L0[q] = load(min(r_first - 1 + q, last_row));
 #pragma unroll
     for (int l = 0; l < T; ++l)
 #pragma unroll
@@ -610,63 +638,67 @@ __device__ __forceinline__ void sweepO_march(const double* __restrict__ in, doub
     for (int k0 = 0; k0 < niter; k0 += 6) {
 #pragma unroll
         for (int u = 0; u < 6; ++u) {
-            const int k = k0 + u;
-            if (k < niter) {  // wave-uniform
-                const int r = r_first + k;
+            {
+                const int r = r_first + k0 + u;
 #pragma unroll
                 for (int l = 1; l <= T; ++l) {
                     const int rho = r - l + 1;
                     const double2 s = (l == 1) ? L0[u % 6] : L[l - 1][(u + 1) % 3];
                     const double2 c = (l == 1) ? L0[(u + 1) % 6] : L[l - 1][(u + 2) % 3];
                     const double2 n = (l == 1) ? L0[(u + 2) % 6] : L[l - 1][u % 3];
+                    // The stencil is evaluated on every lane and row (branch-free, the same code as
+                    // the interior body); where the result is a ghost cell of a physical edge it is
+                    // then replaced by the boundary rule in rarely taken, wave-uniform side blocks.
                     double2 o;
-                    bool ghost_row = false;
-                    if (EDGE && l < T) {
-                        const bool gb = rho == 0 && kb != 3, gt = rho == ny + 1 && kt != 3;
-                        ghost_row = gb || gt;
-                        if (ghost_row) {
-                            const int kk = gb ? kb : kt;
-                            if (kk == CSIM_BC_DIRICHLET)
-                                o = make_double2(bc.value, bc.value);
-                            else if (kk == CSIM_BC_PERIODIC)
-                                o = c;
-                            else if (gt)
-                                o = L[l][(u + 2) % 3];  // Neumann top: row ny of this level
-                            else
-                                o = make_double2(0.0, 0.0);  // Neumann bottom: patched below
-                        }
-                    }
-                    if (!ghost_row) {
+                    {
                         const double Wx = shift_from_prev(c.y);
                         const double Ey = shift_from_next(c.x);
                         o.x = cell<DIV, SX, SY>(c.x, Wx, c.y, s.x, n.x, p);
                         o.y = cell<DIV, SX, SY>(c.y, c.x, Ey, s.y, n.y, p);
-                        if (EDGE && l < T) {  // ghost columns of this level on a physical edge
-                            if (kl != 3 && gy == -1)
-                                o.y = kl == CSIM_BC_DIRICHLET ? bc.value : kl == CSIM_BC_PERIODIC ? c.y : 0.0;
-                            if (kr != 3 && gx == nx)
-                                o.x = kr == CSIM_BC_DIRICHLET ? bc.value : kr == CSIM_BC_PERIODIC ? c.x : 0.0;
-                            if (kr != 3 && gy == nx)
-                                o.y = kr == CSIM_BC_DIRICHLET ? bc.value : kr == CSIM_BC_PERIODIC ? c.y : o.x;
+                    }
+                    if (EDGE && l < T) {
+                        const bool gb = rho == 0 && kb != 3, gt = rho == ny + 1 && kt != 3;
+                        if (gb || gt) {  // ghost ROW of this level
+                            keep_branch();
+                            const int kk = gb ? kb : kt;
+                            if (kk != CSIM_BC_NEUMANN)
+                                o = c;  // Dirichlet / Periodic ghosts keep their level-0 value (bc.value / stored)
+                            else if (gt)
+                                o = L[l][(u + 2) % 3];  // Neumann top: row ny of this level
+                            // (Neumann bottom: patched below as soon as row 1 of this level exists)
+                        } else if (ghost_cols) {  // ghost COLUMNS of this level (first / last strip)
+                            keep_branch();
                             if (kl == CSIM_BC_NEUMANN) {  // left ghost (.y of its lane) := column 0 (.x of the next lane)
+                                keep_branch();
                                 const double nb = shift_from_next(o.x);
-                                if (gy == -1) o.y = nb;
+                                o.y = ghost_ly ? nb : o.y;
+                            } else if (kl != 3) {  // Dirichlet / Periodic: unchanged through the levels
+                                keep_branch();
+                                o.y = ghost_ly ? c.y : o.y;
                             }
-                            if (kr == CSIM_BC_NEUMANN) {  // right ghost held in .x := column nx-1 (.y of the previous lane)
+                            if (kr == CSIM_BC_NEUMANN) {  // right ghost := column nx-1 (.y of the previous lane, or own .x)
+                                keep_branch();
                                 const double pb = shift_from_prev(o.y);
-                                if (gx == nx) o.x = pb;
+                                o.x = ghost_rx ? pb : o.x;
+                                o.y = ghost_ry ? o.x : o.y;
+                            } else if (kr != 3) {
+                                keep_branch();
+                                o.x = ghost_rx ? c.x : o.x;
+                                o.y = ghost_ry ? c.y : o.y;
                             }
                         }
                     }
                     if (l < T) {
-                        if (EDGE && rho == 1 && kb == CSIM_BC_NEUMANN) L[l][(u + 2) % 3] = o;  // ghost row 0 := row 1
+                        if (EDGE && rho == 1 && kb == CSIM_BC_NEUMANN) {  // ghost row 0 := row 1
+                            keep_branch();
+                            L[l][(u + 2) % 3] = o;
+                        }
                         L[l][u % 3] = o;
-                    } else if (rho >= jb && out_lane) {
+                    } else if (rho >= jb && rho <= je && out_lane) {
                         store_pair(out + static_cast<ptrdiff_t>(rho) * pitch + xoff, o.x, o.y, nvalid);
                     }
                 }
-                const int rn = r + 5;
-                if (rn <= last_row) L0[u % 6] = load(rn);
+                L0[u % 6] = load(min(r + 5, last_row));  // row r-1 is dead: its slot takes row r+5
             }
         }
     }
@@ -680,7 +712,12 @@ __global__ __launch_bounds__(256) void k_sweepO_dpp(const double* __restrict__ i
     constexpr int TP = OverlapGeom<T>::TP;
     constexpr int STRIDE = OverlapGeom<T>::STRIDE;
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    // readfirstlane: tells the compiler the wave index (and the strip, edge kinds and row range
+    // derived from it) is wave-uniform, so those tests become scalar branches
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef CSIM_TRACE
+    WaveTrace trace_scope(blockIdx.x * 4 + wave, lane);
+#endif
     int wgx, chunk, side = -1;
     if (part == 1 && nchunks >= 2) {
         const int b = blockIdx.x;
@@ -1463,6 +1500,9 @@ static hipError_t sweepO_div(const double* in, double* out, int nx, int ny, int 
     if (ry <= 0) {
         ry = 64;
         while (ry > 16 && static_cast<long>(nstrips) * cdiv(ny, ry) < 8192) ry >>= 1;
+        // the march runs whole groups of six iterations: make ry + 2 (T - 1) a multiple of six so
+        // that only a ragged last chunk computes surplus rows
+        ry += (6 - (ry + 2 * (T - 1)) % 6) % 6;
     }
     if (ry > ny) ry = ny;
     const int nchunks = cdiv(ny, ry);
