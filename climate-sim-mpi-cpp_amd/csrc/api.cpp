@@ -118,6 +118,7 @@ struct csim_stepper {
     double* scratch = nullptr;
     double* send[4]{nullptr, nullptr, nullptr, nullptr};
     double* recv[4]{nullptr, nullptr, nullptr, nullptr};
+    double* fin[4]{nullptr, nullptr, nullptr, nullptr};  // FinLines of the last fused pass of a run (all sides)
     hipStream_t s_comp = nullptr, s_comm = nullptr;
     hipStream_t s_frame = nullptr;  // high priority: frame tiles + face packing of a fused multi-rank pass
     hipEvent_t ev_edge = nullptr, ev_recv = nullptr, ev_ready = nullptr;
@@ -410,6 +411,10 @@ int csim_stepper_create(const csim_decomp* dec, double dx, double dy, const int 
         ok(hipEventCreateWithFlags(&s->ev_edge, hipEventDisableTiming)) &&
         ok(hipEventCreateWithFlags(&s->ev_recv, hipEventDisableTiming));
     for (int k = 0; k < 4 && e == hipSuccess; ++k) {
+        const size_t nf = sizeof(double) * static_cast<size_t>(k < 2 ? s->ny : s->nx);
+        ok(hipMalloc(reinterpret_cast<void**>(&s->fin[k]), nf)) && ok(hipMemset(s->fin[k], 0, nf));
+    }
+    for (int k = 0; k < 4 && e == hipSuccess; ++k) {
         if (s->phys[k]) continue;
         const size_t n = sizeof(double) * static_cast<size_t>(k < 2 ? s->ny : s->nx);
         ok(hipMalloc(reinterpret_cast<void**>(&s->send[k]), n)) &&
@@ -490,6 +495,7 @@ int csim_stepper_destroy(csim_stepper* s) {
     for (int k = 0; k < 4; ++k) {
         if (s->send[k]) (void)hipFree(s->send[k]);
         if (s->recv[k]) (void)hipFree(s->recv[k]);
+        if (s->fin[k]) (void)hipFree(s->fin[k]);
     }
     for (int d = 0; d < 8; ++d) {
         if (s->send2[d]) (void)hipFree(s->send2[d]);
@@ -855,15 +861,20 @@ static int pass_single(csim_stepper* s, const Phys& p, const GhostArgs& g) {
 // computed first, their depth-next_T faces packed and sent on the comm stream, and the exchange
 // overlaps the rest of the sweep.
 static hipError_t launch_fused(csim_stepper* s, const Phys& p, const int kind[4], int T, int part,
-                               hipStream_t st) {
+                               hipStream_t st, bool final_pass = false) {
     if (s->cfg.multistep == MS_OVERLAP)
-        return launch_sweepO(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, s->cfg, kind, s->bc_value, T, part, st);
+        return launch_sweepO(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, s->cfg, kind, s->bc_value, T, part, st,
+                             final_pass ? s->fin : nullptr);
     if (T == 2)
         return launch_sweep2(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, s->cfg, kind, s->bc_value, part, st);
     return launch_sweepT(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, s->cfg, kind, s->bc_value, T, part, st);
 }
 
-static int pass_fused(csim_stepper* s, const Phys& p, int T, int next_T) {
+// final_pass (overlapped-strip kernels only): the last pass of a run.  The kernel also emits the
+// FinLines (level T-1 = the state before the last step) and a closing ghost fill turns them into
+// the ghost ring the reference leaves behind — halos and boundary values of the state BEFORE the
+// last step (src/main.cpp:102-104 + src/diffusion.cpp:18-25) — without a trailing one-step pass.
+static int pass_fused(csim_stepper* s, const Phys& p, int T, int next_T, bool final_pass = false) {
     const bool rccl = s->multi && !s->external;
     int kind[4];
     for (int k = 0; k < 4; ++k) kind[k] = s->phys[k] ? s->bc[k] : 3;
@@ -900,13 +911,21 @@ static int pass_fused(csim_stepper* s, const Phys& p, int T, int next_T) {
         CSIM_HIP(hipStreamWaitEvent(s->s_comp, s->ev_edge2, 0));  // the pass ends when both parts have
         s->faces_depth = next_T;
     } else {
-        CSIM_HIP(launch_fused(s, p, kind, T, 0, s->s_comp));
+        CSIM_HIP(launch_fused(s, p, kind, T, 0, s->s_comp, final_pass));
         s->faces_depth = 0;
     }
     rc = prof_end(s);
     if (rc) return rc;
     std::swap(s->cur, s->nxt);
     s->halo_fresh = false;
+    if (final_pass) {
+        GhostArgs gf = ghost_args(s);
+        for (int k = 0; k < 4; ++k) {
+            gf.recv[k] = s->phys[k] ? nullptr : s->fin[k];  // the neighbour's edge line before the last step
+            gf.adj[k] = s->phys[k] ? s->fin[k] : nullptr;   // own adjacent interior line before the last step
+        }
+        CSIM_HIP(launch_ghost_fill(s->cur, s->nxt, s->nx, s->ny, s->pitch, gf, s->s_comp));
+    }
     return CSIM_OK;
 }
 
@@ -931,17 +950,27 @@ int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy,
     const Phys p = make_phys(s->dx, s->dy, D, dt, vx, vy);
     const GhostArgs g = ghost_args(s);
     if (s->multi && s->external && nsteps >= 2) return pass_fused(s, p, nsteps, 0);
-    // The LAST step of a call is always a single-step pass so that the ghost ring left in the
-    // field is exactly the reference's (the ring of the state before the last step,
-    // src/main.cpp:104 + src/diffusion.cpp:18-25).
-    auto pass_len = [&](int remaining) { return (can_fuse && remaining >= 3) ? std::min(depth, remaining - 1) : 1; };
+    // The ghost ring left in the field must be exactly the reference's: the halos / boundary values
+    // of the state before the LAST step (src/main.cpp:104 + src/diffusion.cpp:18-25).
+    //  - overlapped-strip kernels: every pass is fused, the last one as `final_pass` (see
+    //    pass_fused); a run is never split so that a single step remains at the end;
+    //  - edge-lane-extras kernels (option multistep = 1): the last step is a one-step pass.
+    const bool tailless = can_fuse && s->cfg.multistep == MS_OVERLAP;
+    auto pass_len = [&](int remaining) {
+        if (!can_fuse) return 1;
+        if (!tailless) return remaining >= 3 ? std::min(depth, remaining - 1) : 1;
+        if (remaining < 2) return 1;
+        const int t = std::min(depth, remaining);
+        return (remaining - t == 1 && t > 2) ? t - 1 : t;
+    };
     int remaining = nsteps;
     while (remaining > 0) {
         const int t = pass_len(remaining);
         int rc;
         if (t >= 2) {
             const int nt = pass_len(remaining - t);
-            rc = pass_fused(s, p, t, nt >= 2 ? nt : 0);
+            const bool last = remaining == t;
+            rc = pass_fused(s, p, t, (!last && nt >= 2) ? nt : 0, tailless && last);
         } else {
             rc = pass_single(s, p, g);
         }

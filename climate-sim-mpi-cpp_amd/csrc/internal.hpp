@@ -83,9 +83,11 @@ hipError_t launch_sweep2(const double* in, double* out, int nx, int ny, int pitc
 hipError_t launch_sweepT(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
                          const SweepCfg& cfg, const int kind[4], double value, int T, int part,
                          hipStream_t st);
+// fin_lines (last pass of a run, all four or nullptr): per side the level T-1 line the final ghost
+// fill needs — see FinLines in kernels.hip
 hipError_t launch_sweepO(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
                          const SweepCfg& cfg, const int kind[4], double value, int T, int part,
-                         hipStream_t st);
+                         hipStream_t st, double* const fin_lines[4] = nullptr);
 constexpr int MAX_FUSE = 6;       // deepest temporal blocking (overlapped-strip kernel; the extras kernels stop at 4)
 constexpr int GHOST_EXTRA = 5;    // device-only ghost layers beyond the reference's one (= MAX_FUSE-1)
 // faces of depth H = 2..4 (8 directions: L R B T BL BR TL TR; nullptr = no neighbour there);
@@ -107,6 +109,7 @@ struct GhostArgs {
     int phys[4];          // side is a physical edge (no neighbour)
     double value;
     const double* recv[4];  // per side: staged halo from the neighbour (nullptr on physical sides)
+    const double* adj[4];   // per side: adjacent interior line to read instead of the field (nullptr = the field)
 };
 // boundary fill (+ unpack of received halos) written to `a` and, when b != nullptr, to `b` too
 // ext_depth > 0 additionally continues each physical Dirichlet/Neumann edge over that many halo

@@ -589,6 +589,16 @@ struct WaveTrace {
 // branch instead of being if-converted into per-lane selects on the hot path.
 __device__ __forceinline__ void keep_branch() { asm volatile(""); }
 
+// Last pass of a run: the kernel also leaves, per side, the line of level T-1 (the state before
+// the last step) that the reference's final halo exchange + apply_boundary would have read, so
+// that the ghost ring of the result can be made exactly the reference's without a trailing
+// single-step pass.  Physical side: the adjacent interior line (column 1 / nx, row 1 / ny);
+// neighbour side: the ghost line itself (column 0 / nx+1, row 0 / ny+1), which this rank computes
+// anyway from the deep faces — bitwise what the neighbour holds there.
+struct FinLines {
+    double* line[4];  // left/right: ny entries; bottom/top: nx entries; all nullptr = off
+};
+
 template <int T>
 struct OverlapGeom {
     static constexpr int TP = 2 * ((T + 1) / 2);       // T rounded up to even
@@ -598,7 +608,8 @@ struct OverlapGeom {
 template <int DIV, int T, bool EDGE, int SX, int SY>
 __device__ __forceinline__ void sweepO_march(const double* __restrict__ in, double* __restrict__ out,
                                              int nx, int ny, int pitch, int jb, int je, int g0, int lane,
-                                             int kl, int kr, const Phys& p, const Bc2& bc) {
+                                             int kl, int kr, const Phys& p, const Bc2& bc,
+                                             const FinLines& fin, bool fin_l, bool fin_r) {
     constexpr int TP = OverlapGeom<T>::TP;
     constexpr int STRIDE = OverlapGeom<T>::STRIDE;
     // this lane's two columns, 0-based interior index (-1 = left ghost, nx = right ghost)
@@ -612,6 +623,7 @@ __device__ __forceinline__ void sweepO_march(const double* __restrict__ in, doub
     const bool ghost_ly = kl != 3 && gy == -1;
     const bool ghost_rx = kr != 3 && gx == nx, ghost_ry = kr != 3 && gy == nx;
     const bool ghost_cols = kl != 3 || kr != 3;  // wave-uniform
+    const bool fin_any = fin.line[CSIM_BOTTOM] != nullptr;  // all four are set together
 
     auto load = [&](int j) {
         return *reinterpret_cast<const double2*>(in + static_cast<ptrdiff_t>(j) * pitch + xoff);
@@ -688,6 +700,19 @@ __device__ __forceinline__ void sweepO_march(const double* __restrict__ in, doub
                             }
                         }
                     }
+                    if (EDGE && T >= 2 && l == T - 1 && fin_any) {  // see FinLines
+                        keep_branch();
+                        if (rho >= jb && rho <= je) {
+                            if (fin_l && (kl != 3 ? gx == 0 : gy == -1)) fin.line[CSIM_LEFT][rho - 1] = kl != 3 ? o.x : o.y;
+                            if (fin_r) {
+                                const int col = kr != 3 ? nx - 1 : nx;
+                                if (gx == col) fin.line[CSIM_RIGHT][rho - 1] = o.x;
+                                if (gy == col) fin.line[CSIM_RIGHT][rho - 1] = o.y;
+                            }
+                        }
+                        if (jb == 1 && rho == (kb != 3 ? 1 : 0) && out_lane) store_pair(fin.line[CSIM_BOTTOM] + gx, o.x, o.y, nvalid);
+                        if (je == ny && rho == (kt != 3 ? ny : ny + 1) && out_lane) store_pair(fin.line[CSIM_TOP] + gx, o.x, o.y, nvalid);
+                    }
                     if (l < T) {
                         if (EDGE && rho == 1 && kb == CSIM_BC_NEUMANN) {  // ghost row 0 := row 1
                             keep_branch();
@@ -708,7 +733,8 @@ template <int DIV, int T, int SX, int SY>
 __global__ __launch_bounds__(256) void k_sweepO_dpp(const double* __restrict__ in,
                                                     double* __restrict__ out, int nx, int ny,
                                                     int pitch, int ry, int nstrips, int nwgx,
-                                                    int nchunks, int part, int swz, Phys p, Bc2 bc) {
+                                                    int nchunks, int part, int swz, Phys p, Bc2 bc,
+                                                    FinLines fin) {
     constexpr int TP = OverlapGeom<T>::TP;
     constexpr int STRIDE = OverlapGeom<T>::STRIDE;
     const int lane = threadIdx.x & 63;
@@ -747,12 +773,14 @@ __global__ __launch_bounds__(256) void k_sweepO_dpp(const double* __restrict__ i
     // nx) lies inside every strip whose 128 loaded columns reach it
     const int kl = first ? bc.kind[CSIM_LEFT] : 3;
     const int kr = g0 + WAVE_COLS > nx ? bc.kind[CSIM_RIGHT] : 3;
+    // on the last pass of a run the frame tiles also take the edge body: they emit the FinLines
+    const bool fin_frame = fin.line[CSIM_BOTTOM] != nullptr && (first || last || jb == 1 || je == ny);
     const bool edge = kl != 3 || kr != 3 || (bc.kind[CSIM_BOTTOM] != 3 && jb - (T - 1) < 1) ||
-                      (bc.kind[CSIM_TOP] != 3 && je + (T - 1) > ny);
+                      (bc.kind[CSIM_TOP] != 3 && je + (T - 1) > ny) || fin_frame;
     if (edge)
-        sweepO_march<DIV, T, true, SX, SY>(in, out, nx, ny, pitch, jb, je, g0, lane, kl, kr, p, bc);
+        sweepO_march<DIV, T, true, SX, SY>(in, out, nx, ny, pitch, jb, je, g0, lane, kl, kr, p, bc, fin, first, last);
     else
-        sweepO_march<DIV, T, false, SX, SY>(in, out, nx, ny, pitch, jb, je, g0, lane, kl, kr, p, bc);
+        sweepO_march<DIV, T, false, SX, SY>(in, out, nx, ny, pitch, jb, je, g0, lane, kl, kr, p, bc, fin, false, false);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -1075,6 +1103,7 @@ struct GhostDev {
     int phys[4];
     double value;
     const double* recv[4];
+    const double* adj[4];  // != nullptr: the adjacent interior line of that side is read from here, not from `a`
     int ext_depth;  // > 0: also continue physical edges over that many halo cells (see ghost_extend_cell)
 };
 
@@ -1124,7 +1153,7 @@ __global__ __launch_bounds__(256) void k_ghost_fill(double* __restrict__ a, doub
                 if (g.bc[s] == CSIM_BC_DIRICHLET)
                     put(at(ig, j, pitch), g.value);
                 else if (g.bc[s] == CSIM_BC_NEUMANN)
-                    put(at(ig, j, pitch), a[at(ia, j, pitch)]);
+                    put(at(ig, j, pitch), g.adj[s] ? g.adj[s][t] : a[at(ia, j, pitch)]);
             } else if (g.recv[s]) {
                 put(at(ig, j, pitch), g.recv[s][t]);
             }
@@ -1139,7 +1168,7 @@ __global__ __launch_bounds__(256) void k_ghost_fill(double* __restrict__ a, doub
                 if (g.bc[s] == CSIM_BC_DIRICHLET)
                     put(at(i, jg, pitch), g.value);
                 else if (g.bc[s] == CSIM_BC_NEUMANN)
-                    put(at(i, jg, pitch), a[at(i, ja, pitch)]);
+                    put(at(i, jg, pitch), g.adj[s] ? g.adj[s][t] : a[at(i, ja, pitch)]);
             } else if (g.recv[s]) {
                 put(at(i, jg, pitch), g.recv[s][t]);
             }
@@ -1170,7 +1199,7 @@ __global__ __launch_bounds__(256) void k_ghost_fill(double* __restrict__ a, doub
                     if (col_d)
                         v = g.value;
                     else if (col_n)
-                        v = a[at(ia, ja, pitch)];
+                        v = g.adj[cs] ? g.adj[cs][ja - 1] : a[at(ia, ja, pitch)];
                     else if (!g.phys[cs] && g.recv[cs])
                         v = g.recv[cs][ja - 1];
                     else
@@ -1493,7 +1522,7 @@ static hipError_t sweepT_div(const double* in, double* out, int nx, int ny, int 
 
 template <int DIV, int T>
 static hipError_t sweepO_div(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
-                             const SweepCfg& cfg, const Bc2& bc, int part, hipStream_t st) {
+                             const SweepCfg& cfg, const Bc2& bc, const FinLines& fin, int part, hipStream_t st) {
     constexpr int STRIDE = OverlapGeom<T>::STRIDE;
     const int nstrips = cdiv(nx, STRIDE);
     int ry = cfg.rows_per_chunk;
@@ -1515,7 +1544,7 @@ static hipError_t sweepO_div(const double* in, double* out, int nx, int ny, int 
     const int sign = (p.vx >= 0.0 ? 2 : 0) + (p.vy >= 0.0 ? 1 : 0);
 #define CSIM_LAUNCH_O(SXV, SYV)                                                                        \
     hipLaunchKernelGGL((k_sweepO_dpp<DIV, T, SXV, SYV>), grid, block, 0, st, in, out, nx, ny, pitch, ry, \
-                       nstrips, nwgx, nchunks, part, sw, p, bc)
+                       nstrips, nwgx, nchunks, part, sw, p, bc, fin)
     switch (sign) {
         case 3: CSIM_LAUNCH_O(1, 1); break;
         case 2: CSIM_LAUNCH_O(1, 0); break;
@@ -1528,27 +1557,29 @@ static hipError_t sweepO_div(const double* in, double* out, int nx, int ny, int 
 
 template <int T>
 static hipError_t sweepO_T(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
-                           const SweepCfg& cfg, const Bc2& bc, int part, hipStream_t st) {
+                           const SweepCfg& cfg, const Bc2& bc, const FinLines& fin, int part, hipStream_t st) {
     switch (p.div_mode) {
-        case 0: return sweepO_div<0, T>(in, out, nx, ny, pitch, p, cfg, bc, part, st);
-        case 1: return sweepO_div<1, T>(in, out, nx, ny, pitch, p, cfg, bc, part, st);
-        default: return sweepO_div<2, T>(in, out, nx, ny, pitch, p, cfg, bc, part, st);
+        case 0: return sweepO_div<0, T>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st);
+        case 1: return sweepO_div<1, T>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st);
+        default: return sweepO_div<2, T>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st);
     }
 }
 
 // overlapped-strip multi-step sweep, T = 2..6 (same kind[] / part conventions as launch_sweep2)
 hipError_t launch_sweepO(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
                          const SweepCfg& cfg, const int kind[4], double value, int T, int part,
-                         hipStream_t st) {
+                         hipStream_t st, double* const fin_lines[4]) {
     Bc2 bc;
     for (int s = 0; s < 4; ++s) bc.kind[s] = kind[s];
     bc.value = value;
+    FinLines fin;
+    for (int s = 0; s < 4; ++s) fin.line[s] = fin_lines ? fin_lines[s] : nullptr;
     switch (T) {
-        case 2: return sweepO_T<2>(in, out, nx, ny, pitch, p, cfg, bc, part, st);
-        case 3: return sweepO_T<3>(in, out, nx, ny, pitch, p, cfg, bc, part, st);
-        case 4: return sweepO_T<4>(in, out, nx, ny, pitch, p, cfg, bc, part, st);
-        case 5: return sweepO_T<5>(in, out, nx, ny, pitch, p, cfg, bc, part, st);
-        default: return sweepO_T<6>(in, out, nx, ny, pitch, p, cfg, bc, part, st);
+        case 2: return sweepO_T<2>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st);
+        case 3: return sweepO_T<3>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st);
+        case 4: return sweepO_T<4>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st);
+        case 5: return sweepO_T<5>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st);
+        default: return sweepO_T<6>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st);
     }
 }
 
@@ -1657,6 +1688,7 @@ hipError_t launch_ghost_fill(double* a, double* b, int nx, int ny, int pitch, co
         d.bc[s] = g.bc[s];
         d.phys[s] = g.phys[s];
         d.recv[s] = g.recv[s];
+        d.adj[s] = g.adj[s];
     }
     d.value = g.value;
     const int n = (nx > ny ? nx : ny) + 1 + 8 * ext_depth;

@@ -39,8 +39,8 @@ def main():
         st.set_option("profile", 1)
         cfgs = []
         for v in args.variants:
-            if v == 1:
-                cfgs += [dict(variant=1, rows_per_chunk=r, prefetch=p, xcd_swizzle=s, fuse=f, wide=w, stagger=g,
+            if v in (0, 1):
+                cfgs += [dict(variant=v, rows_per_chunk=r, prefetch=p, xcd_swizzle=s, fuse=f, wide=w, stagger=g,
                               multistep=m)
                          for r, p, s, f, w, g, m in itertools.product(args.ry, args.pf, args.swz, args.fuse,
                                                                       args.wide, args.stagger, args.multistep)
