@@ -72,8 +72,11 @@ def cpu_baseline(cores: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--ramp-seconds", type=float, default=0.3,
+                    help="untimed stepping before the warm-up steps so that the GPU has left its idle "
+                         "clocks (a cold MI355X runs its first ~30 ms about 15 %% below the sustained rate)")
     ap.add_argument("--nx", type=int, default=NX)
     ap.add_argument("--ny", type=int, default=NY)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -142,6 +145,20 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # untimed: clock ramp (also triggers the stepper's one-off rows-per-chunk trial), then W warm-up steps
+    ramp_steps = 0
+    t_ramp = time.perf_counter()
+    while args.ramp_seconds > 0:
+        st.run(PHYS["D"], dt, PHYS["vx"], PHYS["vy"], 60)
+        st.sync()
+        ramp_steps += 60
+        done = time.perf_counter() - t_ramp >= args.ramp_seconds
+        if world > 1:  # every rank must take the same number of steps: decide together
+            t = torch.tensor([1 if done else 0], dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            done = bool(t.item())
+        if done:
+            break
     st.run(PHYS["D"], dt, PHYS["vx"], PHYS["vy"], args.warmup)
     barrier()
     st.set_option("profile", 1)
@@ -161,6 +178,7 @@ def main():
     steps_per_launch = max(kinds, key=lambda t: t * kinds[t][1])
     kern_ms, launches = kinds[steps_per_launch]
     mn, mx = st.minmax()
+    tuned_rows = st.get_option("tuned_rows") or (args.rows_per_chunk or "heuristic")
     mass1 = global_sum()
     mass_drift = abs(mass1 - mass0) / abs(mass0)
     if mass_drift > 1e-9 and rank == 0:
@@ -212,6 +230,8 @@ def main():
                 "hbm_gbs_whole_job": cells * args.steps * BYTES_PER_CELL / elapsed / 1e9,
                 "field_min_max_after_run": [mn, mx],
                 "relative_mass_drift": mass_drift,
+                "untimed_clock_ramp_steps": ramp_steps,
+                "rows_per_chunk": tuned_rows,
             },
             "roofline": {
                 "bound": "hbm",

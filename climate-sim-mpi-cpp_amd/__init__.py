@@ -134,6 +134,7 @@ def lib() -> C.CDLL:
         "csim_stepper_minmax": (i, [vp, dp]),
         "csim_stepper_sum": (i, [vp, dp]),
         "csim_stepper_set_option": (i, [vp, C.c_char_p, C.c_long]),
+        "csim_stepper_get_option": (i, [vp, C.c_char_p, C.POINTER(C.c_long)]),
         "csim_stepper_kernel_time": (i, [vp, i, dp, C.POINTER(C.c_long)]),
         "csim_stepper_reset_timers": (i, [vp]),
     }
@@ -401,6 +402,11 @@ class Stepper:
 
     def set_option(self, key: str, value: int):
         _ck(lib().csim_stepper_set_option(self._h, key.encode(), int(value)))
+
+    def get_option(self, key: str) -> int:
+        v = C.c_long()
+        _ck(lib().csim_stepper_get_option(self._h, key.encode(), C.byref(v)))
+        return v.value
 
     def kernel_time(self, steps_per_launch=None):
         """(total ms, launches) of the timed sweep launches of one kind (1 or 2 steps per launch);

@@ -150,6 +150,8 @@ struct csim_stepper {
     int fuse = -1;  // time steps per HBM pass: -1 auto, 0/1 off, 2..4 depth (multi-rank runs cap at 2)
     int external = 0;  // halos are carried by the caller (csim_stepper_halo_pack/_unpack), not RCCL
     int profile = 0;
+    int autotune = 1;     // pick rows_per_chunk (when 0 = auto) by timing trial launches on this GPU
+    bool tuned = false;
     std::vector<hipEvent_t> ev_pool;  // start/stop pairs around sweep launches
     std::vector<int> ev_steps;        // time steps covered by each timed launch
     size_t ev_used = 0;
@@ -929,6 +931,60 @@ static int pass_fused(csim_stepper* s, const Phys& p, int T, int next_T, bool fi
     return CSIM_OK;
 }
 
+// Rows per chunk of the fused sweep by trial: how a launch's wavefronts tile the 256 CUs (rounds
+// of 4096 resident wavefronts, overhead rows per chunk) depends on the tile shape in a way no
+// closed formula caught (tools/sweep_variants.py scans), so the stepper times the candidates on
+// its own tile once: cur -> nxt launches WITHOUT a swap, i.e. the field is not advanced and the
+// scratch interior written to nxt is overwritten by the next real pass.  Results never depend on
+// the choice.  Ranks tune independently (no communication involved).
+static int tune_rows(csim_stepper* s, const Phys& p, int T) {
+    s->tuned = true;
+    std::vector<int> cand;
+    for (int ry = 14; ry <= 160 && ry <= s->ny; ry += 6) {
+        const int snapped = ry + (6 - (ry + 2 * (T - 1)) % 6) % 6;
+        if (snapped <= s->ny && (cand.empty() || cand.back() != snapped)) cand.push_back(snapped);
+    }
+    if (cand.size() < 2) return CSIM_OK;
+    int kind[4];
+    for (int k = 0; k < 4; ++k) kind[k] = s->phys[k] ? s->bc[k] : 3;
+    hipEvent_t e0, e1;
+    CSIM_HIP(hipEventCreate(&e0));
+    CSIM_HIP(hipEventCreate(&e1));
+    CSIM_HIP(hipStreamSynchronize(s->s_comp));
+    SweepCfg cfg = s->cfg;
+    auto trial = [&](int ry, float* ms) -> int {
+        cfg.tuned_rows = ry;
+        CSIM_HIP(hipEventRecord(e0, s->s_comp));
+        CSIM_HIP(launch_sweepO(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, cfg, kind, s->bc_value, T, 0, s->s_comp));
+        CSIM_HIP(hipEventRecord(e1, s->s_comp));
+        CSIM_HIP(hipEventSynchronize(e1));
+        CSIM_HIP(hipEventElapsedTime(ms, e0, e1));
+        return CSIM_OK;
+    };
+    // bring the clocks up first (a cold GPU runs its first ~20 ms well below the sustained rate)
+    float ms = 0.f, spent = 0.f;
+    for (int k = 0; k < 64 && spent < 30.f; ++k) {
+        int rc = trial(cand[cand.size() / 2], &ms);
+        if (rc) return rc;
+        spent += ms;
+    }
+    std::vector<float> best(cand.size(), 1e30f);
+    for (int round = 0; round < 3; ++round)
+        for (size_t c = 0; c < cand.size(); ++c) {
+            const size_t idx = (round & 1) ? cand.size() - 1 - c : c;  // alternate the order: drift cancels
+            int rc = trial(cand[idx], &ms);
+            if (rc) return rc;
+            best[idx] = std::min(best[idx], ms);
+        }
+    size_t arg = 0;
+    for (size_t c = 1; c < cand.size(); ++c)
+        if (best[c] < best[arg]) arg = c;
+    s->cfg.tuned_rows = cand[arg];
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return CSIM_OK;
+}
+
 int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy, int nsteps) {
     CSIM_REQUIRE(s, "null stepper");
     CSIM_REQUIRE(nsteps >= 0, "nsteps must be >= 0");
@@ -956,6 +1012,10 @@ int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy,
     //    pass_fused); a run is never split so that a single step remains at the end;
     //  - edge-lane-extras kernels (option multistep = 1): the last step is a one-step pass.
     const bool tailless = can_fuse && s->cfg.multistep == MS_OVERLAP;
+    if (tailless && s->autotune && !s->tuned && s->cfg.rows_per_chunk == 0 && nsteps >= 4 * depth) {
+        int rc = tune_rows(s, p, depth);
+        if (rc) return rc;
+    }
     auto pass_len = [&](int remaining) {
         if (!can_fuse) return 1;
         if (!tailless) return remaining >= 3 ? std::min(depth, remaining - 1) : 1;
@@ -1033,11 +1093,35 @@ int csim_stepper_set_option(csim_stepper* s, const char* key, long value) {
     } else if (k == "fuse") {
         CSIM_REQUIRE(value >= -1 && value <= MAX_FUSE, "fuse must be -1 (auto) or 0..6");
         s->fuse = static_cast<int>(value);
+    } else if (k == "autotune") {
+        s->autotune = value != 0;
+        s->tuned = false;
+        s->cfg.tuned_rows = 0;
+    } else if (k == "tuned_rows") {  // read back through csim_stepper_get_option
+        return fail(CSIM_ERR_ARG, "tuned_rows is read-only");
     } else if (k == "profile") {
         s->profile = value != 0;
     } else {
         return fail(CSIM_ERR_ARG, "unknown option: " + k);
     }
+    return CSIM_OK;
+}
+
+int csim_stepper_get_option(const csim_stepper* s, const char* key, long* value) {
+    CSIM_REQUIRE(s && key && value, "null argument");
+    const std::string k(key);
+    if (k == "variant") *value = s->cfg.variant;
+    else if (k == "rows_per_chunk") *value = s->cfg.rows_per_chunk;
+    else if (k == "tuned_rows") *value = s->cfg.tuned_rows;
+    else if (k == "prefetch") *value = s->cfg.prefetch;
+    else if (k == "multistep") *value = s->cfg.multistep;
+    else if (k == "xcd_swizzle") *value = s->cfg.xcd_swizzle;
+    else if (k == "overlap") *value = s->overlap;
+    else if (k == "external_halo") *value = s->external;
+    else if (k == "fuse") *value = s->fuse;
+    else if (k == "autotune") *value = s->autotune;
+    else if (k == "profile") *value = s->profile;
+    else return fail(CSIM_ERR_ARG, "unknown option: " + k);
     return CSIM_OK;
 }
 

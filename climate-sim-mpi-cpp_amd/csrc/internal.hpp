@@ -62,6 +62,7 @@ enum { MS_OVERLAP = 0, MS_EXTRAS = 1 };
 struct SweepCfg {
     int variant = VAR_AUTO;
     int rows_per_chunk = 0;  // 0 = auto
+    int tuned_rows = 0;      // auto mode: rows per chunk found by the stepper's on-device trial (0 = heuristic)
     int prefetch = 0;        // 0 = auto (rows kept in flight per wavefront)
     int xcd_swizzle = 1;
     int multistep = MS_OVERLAP;

@@ -1527,8 +1527,12 @@ static hipError_t sweepO_div(const double* in, double* out, int nx, int ny, int 
     const int nstrips = cdiv(nx, STRIDE);
     int ry = cfg.rows_per_chunk;
     if (ry <= 0) {
-        ry = 64;
-        while (ry > 16 && static_cast<long>(nstrips) * cdiv(ny, ry) < 8192) ry >>= 1;
+        if (cfg.tuned_rows > 0) {
+            ry = cfg.tuned_rows;
+        } else {
+            ry = 64;
+            while (ry > 16 && static_cast<long>(nstrips) * cdiv(ny, ry) < 8192) ry >>= 1;
+        }
         // the march runs whole groups of six iterations: make ry + 2 (T - 1) a multiple of six so
         // that only a ragged last chunk computes surplus rows
         ry += (6 - (ry + 2 * (T - 1)) % 6) % 6;

@@ -145,8 +145,8 @@ int csim_stepper_faces_unpack(csim_stepper* s, int depth, const double* const ho
 /* reference src/halo.cpp:6-50  exchange_halos(u, dec, comm) on the current field */
 int csim_stepper_exchange_halos(csim_stepper* s);
 /* nsteps x { exchange_halos; apply_boundary; fused sweep; swap }, enqueued without host syncs;
- * internally up to 6 steps share one pass over HBM, the last step of a call is always a single-step
- * pass (so the ghost ring left in the field is the reference's) */
+ * internally up to 6 steps share one pass over HBM; the last pass of a call also leaves the ghost
+ * ring the reference would (halos / boundary values of the state before the last step) */
 int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy, int nsteps);
 int csim_stepper_sync(csim_stepper* s);
 int csim_stepper_minmax(csim_stepper* s, double out_min_max[2]);
@@ -159,8 +159,12 @@ int csim_stepper_sum(csim_stepper* s, double* out);
  *   "xcd_swizzle"    0/1 XCD-aware block->tile map; "wide", "stagger": measured alternatives, off
  *   "overlap"        0/1 halo exchange on the comm stream concurrently with the sweep
  *   "external_halo"  0/1 the caller carries the faces (csim_stepper_halo_* / _faces_*)
- *   "profile"        0/1 HIP events around every sweep launch (csim_stepper_kernel_time) */
+ *   "profile"        0/1 HIP events around every sweep launch (csim_stepper_kernel_time)
+ *   "autotune"       0/1 (default 1) with rows_per_chunk = 0: the first long run times the candidate
+ *                    chunk heights on this GPU (trial launches that do not advance the field) and keeps
+ *                    the fastest; "tuned_rows" (read-only) reports it */
 int csim_stepper_set_option(csim_stepper* s, const char* key, long value);
+int csim_stepper_get_option(const csim_stepper* s, const char* key, long* value);
 /* with option "profile"=1: HIP-event time (on the compute stream) and count of the sweep
  * launches since the last reset, per kernel kind: steps_per_launch = 1 selects the single-step
  * kernel, 2..6 the kernels that advance that many time steps per HBM pass */
