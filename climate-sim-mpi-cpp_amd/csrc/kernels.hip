@@ -777,9 +777,13 @@ __global__ __launch_bounds__(256) void k_sweepO_dpp(const double* __restrict__ i
     const bool fin_frame = fin.line[CSIM_BOTTOM] != nullptr && (first || last || jb == 1 || je == ny);
     const bool edge = kl != 3 || kr != 3 || (bc.kind[CSIM_BOTTOM] != 3 && jb - (T - 1) < 1) ||
                       (bc.kind[CSIM_TOP] != 3 && je + (T - 1) > ny) || fin_frame;
-    if (edge)
+    if (edge) {
+        // The edge body carries a few scalar tests and branches per level, so its wavefronts have
+        // the longest latency per row and would finish last, leaving the rest of the chip idle
+        // (29 % of a 4096 x 8192 launch, tools/wavetrace.hip): give them issue priority.
+        __builtin_amdgcn_s_setprio(3);
         sweepO_march<DIV, T, true, SX, SY>(in, out, nx, ny, pitch, jb, je, g0, lane, kl, kr, p, bc, fin, first, last);
-    else
+    } else
         sweepO_march<DIV, T, false, SX, SY>(in, out, nx, ny, pitch, jb, je, g0, lane, kl, kr, p, bc, fin, false, false);
 }
 
