@@ -898,19 +898,17 @@ static int pass_fused(csim_stepper* s, const Phys& p, int T, int next_T, bool fi
     int rc = prof_begin(s, T);
     if (rc) return rc;
     if (rccl && s->overlap && next_T >= 2) {
-        // frame tiles + face packing on the high-priority stream, concurrently with the other
-        // tiles on the compute stream; the exchange follows on the comm stream
-        CSIM_HIP(hipEventRecord(s->ev_ready, s->s_comp));
-        CSIM_HIP(hipStreamWaitEvent(s->s_frame, s->ev_ready, 0));
-        CSIM_HIP(launch_fused(s, p, kind, T, 1, s->s_frame));
-        CSIM_HIP(launch_halo2_pack(s->nxt, s->nx, s->ny, s->pitch, next_T, s->send2, s->s_frame));
-        CSIM_HIP(hipEventRecord(s->ev_edge2, s->s_frame));
+        // FRAME tiles first (thin tiles along the four edges, ~15 us), then the BULK on the same
+        // stream; as soon as the frame is done the comm stream packs the NEXT pass's faces from it
+        // and runs the exchange, which the bulk hides
+        CSIM_HIP(launch_fused(s, p, kind, T, 1, s->s_comp));
+        CSIM_HIP(hipEventRecord(s->ev_edge2, s->s_comp));
         CSIM_HIP(hipStreamWaitEvent(s->s_comm, s->ev_edge2, 0));
+        CSIM_HIP(launch_halo2_pack(s->nxt, s->nx, s->ny, s->pitch, next_T, s->send2, s->s_comm));
         rc = post_exchange2(s, next_T, s->s_comm);
         if (rc) return rc;
         CSIM_HIP(hipEventRecord(s->ev_recv2, s->s_comm));
         CSIM_HIP(launch_fused(s, p, kind, T, 2, s->s_comp));
-        CSIM_HIP(hipStreamWaitEvent(s->s_comp, s->ev_edge2, 0));  // the pass ends when both parts have
         s->faces_depth = next_T;
     } else {
         CSIM_HIP(launch_fused(s, p, kind, T, 0, s->s_comp, final_pass));

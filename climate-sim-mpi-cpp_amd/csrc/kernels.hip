@@ -729,12 +729,26 @@ __device__ __forceinline__ void sweepO_march(const double* __restrict__ in, doub
     }
 }
 
+// Tiles of one launch: up to four rectangular regions of (strip, chunk) tiles, numbered
+// consecutively; wavefront w of block b owns tile 4 b + w.  One region (all strips x all rows) is
+// the whole-field launch; a multi-rank pass splits the field into the FRAME (bottom band, top
+// band, left strip(s), right strip(s): thin tiles, finished early so that the faces can travel
+// while the rest computes) and the BULK (everything else).
+struct TileRegion {
+    int t_end;          // tiles [t_end of the previous region, t_end)
+    int strip0, nstrip; // strips strip0 .. strip0 + nstrip - 1
+    int j0, j1, ry;     // rows j0 .. j1 in chunks of ry
+};
+struct Tiling {
+    TileRegion r[4];
+    int nregions, ntiles;
+};
+
 template <int DIV, int T, int SX, int SY>
 __global__ __launch_bounds__(256) void k_sweepO_dpp(const double* __restrict__ in,
                                                     double* __restrict__ out, int nx, int ny,
-                                                    int pitch, int ry, int nstrips, int nwgx,
-                                                    int nchunks, int part, int swz, Phys p, Bc2 bc,
-                                                    FinLines fin) {
+                                                    int pitch, int nstrips, Tiling tl, int swz,
+                                                    Phys p, Bc2 bc, FinLines fin) {
     constexpr int TP = OverlapGeom<T>::TP;
     constexpr int STRIDE = OverlapGeom<T>::STRIDE;
     const int lane = threadIdx.x & 63;
@@ -744,30 +758,21 @@ __global__ __launch_bounds__(256) void k_sweepO_dpp(const double* __restrict__ i
 #ifdef CSIM_TRACE
     WaveTrace trace_scope(blockIdx.x * 4 + wave, lane);
 #endif
-    int wgx, chunk, side = -1;
-    if (part == 1 && nchunks >= 2) {
-        const int b = blockIdx.x;
-        if (b < 2 * nwgx) {
-            chunk = b < nwgx ? 0 : nchunks - 1;
-            wgx = b < nwgx ? b : b - nwgx;
-        } else {
-            chunk = 1 + ((b - 2 * nwgx) >> 1);
-            side = (b - 2 * nwgx) & 1;
-            wgx = side ? nwgx - 1 : 0;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x, swz) * 4 + wave;
+    if (tile >= tl.ntiles) return;  // wave-uniform
+    int t0 = 0, strip0 = tl.r[0].strip0, nstrip = tl.r[0].nstrip, j0 = tl.r[0].j0, j1 = tl.r[0].j1, ry = tl.r[0].ry;
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+        if (q < tl.nregions && tile >= tl.r[q - 1].t_end) {
+            t0 = tl.r[q - 1].t_end;
+            strip0 = tl.r[q].strip0, nstrip = tl.r[q].nstrip, j0 = tl.r[q].j0, j1 = tl.r[q].j1, ry = tl.r[q].ry;
         }
-    } else {
-        const int lin = xcd_remap(blockIdx.x, gridDim.x, swz);
-        wgx = lin % nwgx;
-        chunk = lin / nwgx;
-    }
-    const int strip = wgx * 4 + wave;
-    if (strip >= nstrips) return;  // wave-uniform
+    const int local = tile - t0;
+    const int strip = strip0 + local % nstrip;
+    const int chunk = local / nstrip;
     const bool first = strip == 0, last = strip == nstrips - 1;
-    if (side == 0 && !first) return;
-    if (side == 1 && !last) return;
-    if (part == 2 && (nchunks < 2 || chunk == 0 || chunk == nchunks - 1 || first || last)) return;
-    const int jb = chunk * ry + 1;
-    const int je = min(jb + ry - 1, ny);
+    const int jb = j0 + chunk * ry;
+    const int je = min(jb + ry - 1, j1);
     const int g0 = strip * STRIDE - TP;
     // a strip meets the left ghost column iff it is the first one; the right ghost column (index
     // nx) lies inside every strip whose 128 loaded columns reach it
@@ -1542,17 +1547,39 @@ static hipError_t sweepO_div(const double* in, double* out, int nx, int ny, int 
         ry += (6 - (ry + 2 * (T - 1)) % 6) % 6;
     }
     if (ry > ny) ry = ny;
-    const int nchunks = cdiv(ny, ry);
-    const int nwgx = cdiv(nstrips, 4);
-    int nblocks = nwgx * nchunks;
-    if (part == 1 && nchunks >= 2) nblocks = 2 * nwgx + 2 * (nchunks - 2);
-    if (part == 2 && nchunks < 3) return hipSuccess;  // every tile is a frame tile
-    const dim3 grid(nblocks), block(256);
+    // part 0: the whole field.  part 1 / 2 (multi-rank pass): FRAME / BULK.  The frame is the
+    // bottom and top bands (hf rows, all strips) plus the first strip and the last one or two
+    // strips (>= MAX_FUSE columns) over the rows in between, in chunks of hf rows: thin tiles,
+    // one short round of wavefronts, so the faces are ready ~15 us into the pass.
+    int hf = 12;
+    hf += (6 - (hf + 2 * (T - 1)) % 6) % 6;
+    const int nright = (nx - (nstrips - 1) * STRIDE >= MAX_FUSE) ? 1 : 2;
+    const bool split = ny >= 2 * hf + 1 && nstrips >= nright + 2;
+    Tiling tl{};
+    auto add = [&](int strip0, int nstrip, int j0, int j1, int rows) {
+        if (nstrip <= 0 || j1 < j0) return;
+        TileRegion& r = tl.r[tl.nregions++];
+        r.strip0 = strip0, r.nstrip = nstrip, r.j0 = j0, r.j1 = j1, r.ry = rows;
+        tl.ntiles += nstrip * cdiv(j1 - j0 + 1, rows);
+        r.t_end = tl.ntiles;
+    };
+    if (part == 0 || (part == 1 && !split)) {
+        add(0, nstrips, 1, ny, ry);
+    } else if (part == 1) {
+        add(0, nstrips, 1, hf, hf);
+        add(0, nstrips, ny - hf + 1, ny, hf);
+        add(0, 1, hf + 1, ny - hf, hf);
+        add(nstrips - nright, nright, hf + 1, ny - hf, hf);
+    } else if (split) {
+        add(1, nstrips - 1 - nright, hf + 1, ny - hf, std::min(ry, ny - 2 * hf));
+    }
+    if (tl.ntiles == 0) return hipSuccess;  // part 2 of a field that is all frame
+    const dim3 grid(cdiv(tl.ntiles, 4)), block(256);
     const int sw = cfg.xcd_swizzle;
     const int sign = (p.vx >= 0.0 ? 2 : 0) + (p.vy >= 0.0 ? 1 : 0);
 #define CSIM_LAUNCH_O(SXV, SYV)                                                                        \
-    hipLaunchKernelGGL((k_sweepO_dpp<DIV, T, SXV, SYV>), grid, block, 0, st, in, out, nx, ny, pitch, ry, \
-                       nstrips, nwgx, nchunks, part, sw, p, bc, fin)
+    hipLaunchKernelGGL((k_sweepO_dpp<DIV, T, SXV, SYV>), grid, block, 0, st, in, out, nx, ny, pitch, \
+                       nstrips, tl, sw, p, bc, fin)
     switch (sign) {
         case 3: CSIM_LAUNCH_O(1, 1); break;
         case 2: CSIM_LAUNCH_O(1, 0); break;
