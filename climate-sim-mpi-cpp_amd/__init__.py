@@ -130,6 +130,7 @@ def lib() -> C.CDLL:
         "csim_stepper_faces_pack": (i, [vp, i, C.POINTER(dp)]),
         "csim_stepper_faces_unpack": (i, [vp, i, C.POINTER(dp)]),
         "csim_stepper_run": (i, [vp, d, d, d, d, i]),
+        "csim_stepper_tune": (i, [vp, d, d, d, d]),
         "csim_stepper_sync": (i, [vp]),
         "csim_stepper_minmax": (i, [vp, dp]),
         "csim_stepper_sum": (i, [vp, dp]),
@@ -402,6 +403,9 @@ class Stepper:
 
     def set_option(self, key: str, value: int):
         _ck(lib().csim_stepper_set_option(self._h, key.encode(), int(value)))
+
+    def tune(self, D, dt, vx, vy):
+        _ck(lib().csim_stepper_tune(self._h, D, dt, vx, vy))
 
     def get_option(self, key: str) -> int:
         v = C.c_long()

@@ -937,6 +937,9 @@ static int pass_fused(csim_stepper* s, const Phys& p, int T, int next_T, bool fi
 // the choice.  Ranks tune independently (no communication involved).
 static int tune_rows(csim_stepper* s, const Phys& p, int T) {
     s->tuned = true;
+    // small tiles: a launch takes a few tens of microseconds whatever the chunking, the trial
+    // would cost more than it can win
+    if (static_cast<long>(s->nx) * s->ny < (1L << 22)) return CSIM_OK;
     std::vector<int> cand;
     for (int ry = 14; ry <= 160 && ry <= s->ny; ry += 6) {
         const int snapped = ry + (6 - (ry + 2 * (T - 1)) % 6) % 6;
@@ -981,6 +984,23 @@ static int tune_rows(csim_stepper* s, const Phys& p, int T) {
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return CSIM_OK;
+}
+
+// deepest fused pass of this stepper with the current options (1 = single steps only)
+static int fused_depth(const csim_stepper* s) {
+    int depth = std::min(s->fuse < 0 ? MAX_FUSE : s->fuse, s->fuse_cap);
+    if (s->cfg.multistep == MS_EXTRAS) depth = std::min(depth, 4);
+    const bool dpp_family = s->cfg.variant == VAR_AUTO || s->cfg.variant == VAR_DPP;
+    const bool can_fuse = depth >= 2 && dpp_family && (s->cfg.multistep == MS_OVERLAP || s->widths128);
+    return can_fuse ? depth : 1;
+}
+
+// the one-off trial of csim_stepper_run's first long call, on request (e.g. before a timed loop)
+int csim_stepper_tune(csim_stepper* s, double D, double dt, double vx, double vy) {
+    CSIM_REQUIRE(s, "null stepper");
+    const int depth = fused_depth(s);
+    if (depth < 2 || s->cfg.multistep != MS_OVERLAP || s->tuned || s->cfg.rows_per_chunk != 0) return CSIM_OK;
+    return tune_rows(s, make_phys(s->dx, s->dy, D, dt, vx, vy), depth);
 }
 
 int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy, int nsteps) {

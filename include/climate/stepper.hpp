@@ -66,6 +66,8 @@ class Stepper {
     void run(double D, double dt, double vx, double vy, int nsteps) {
         check(csim_stepper_run(h_, D, dt, vx, vy, nsteps));
     }
+    // one-off chunking trial on this GPU (otherwise done inside the first long run())
+    void tune(double D, double dt, double vx, double vy) { check(csim_stepper_tune(h_, D, dt, vx, vy)); }
     void sync() { check(csim_stepper_sync(h_)); }
     void set_option(const char* key, long v) { check(csim_stepper_set_option(h_, key, v)); }
     void minmax(double& mn, double& mx) {

@@ -148,6 +148,9 @@ int csim_stepper_exchange_halos(csim_stepper* s);
  * internally up to 6 steps share one pass over HBM; the last pass of a call also leaves the ghost
  * ring the reference would (halos / boundary values of the state before the last step) */
 int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy, int nsteps);
+/* optional, before a timed loop: the one-off rows-per-chunk trial that the first long
+ * csim_stepper_run would otherwise do (option "autotune"); does not advance the field */
+int csim_stepper_tune(csim_stepper* s, double D, double dt, double vx, double vy);
 int csim_stepper_sync(csim_stepper* s);
 int csim_stepper_minmax(csim_stepper* s, double out_min_max[2]);
 int csim_stepper_sum(csim_stepper* s, double* out);
