@@ -25,41 +25,8 @@ sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package  # noqa: E402
 from oracle import cpu_oracle as ora  # noqa: E402
 
-OPPOSITE = {0: 1, 1: 0, 2: 3, 3: 2}
-
-
-def exchange(lines, nbr):
-    """send my edge line of side k to nbr[k]; receive the neighbour's (its opposite side)."""
-    reqs, got = [], [None] * 4
-    for k in range(4):
-        if nbr[k] >= 0:
-            got[k] = torch.empty(lines[k].shape[0], dtype=torch.float64)
-            reqs.append(dist.irecv(got[k], src=nbr[k], tag=OPPOSITE[k]))
-    for k in range(4):
-        if nbr[k] >= 0:
-            reqs.append(dist.isend(torch.from_numpy(np.ascontiguousarray(lines[k])), dst=nbr[k], tag=k))
-    for r in reqs:
-        r.wait()
-    return [g.numpy() if g is not None else None for g in got]
-
-
-def opposite8(d):
-    return d ^ 1 if d < 4 else 11 - d
-
-
-def exchange8(faces, peers):
-    """depth-2 faces, 8 directions (L R B T BL BR TL TR); None where there is no peer."""
-    reqs, got = [], [None] * 8
-    for d in range(8):
-        if peers[d] >= 0:
-            got[d] = torch.empty(faces[d].shape[0], dtype=torch.float64)
-            reqs.append(dist.irecv(got[d], src=peers[d], tag=opposite8(d)))
-    for d in range(8):
-        if peers[d] >= 0:
-            reqs.append(dist.isend(torch.from_numpy(np.ascontiguousarray(faces[d])), dst=peers[d], tag=d))
-    for r in reqs:
-        r.wait()
-    return [g.numpy() if g is not None else None for g in got]
+load_package()
+from climate_sim_mpi_cpp_amd.host_transport import exchange, exchange8  # noqa: E402
 
 
 def edges(u, nbr):
