@@ -1551,7 +1551,7 @@ static hipError_t sweepO_div(const double* in, double* out, int nx, int ny, int 
     // bottom and top bands (hf rows, all strips) plus the first strip and the last one or two
     // strips (>= MAX_FUSE columns) over the rows in between, in chunks of hf rows: thin tiles,
     // one short round of wavefronts, so the faces are ready ~15 us into the pass.
-    int hf = 12;
+    int hf = 12;  // >= the deepest face (8-row bands were measured slower: more, even thinner tiles)
     hf += (6 - (hf + 2 * (T - 1)) % 6) % 6;
     const int nright = (nx - (nstrips - 1) * STRIDE >= MAX_FUSE) ? 1 : 2;
     const bool split = ny >= 2 * hf + 1 && nstrips >= nright + 2;
