@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--rows-per-chunk", type=int, default=0)
     ap.add_argument("--prefetch", type=int, default=0)
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--lds-bytes", type=int, default=0, help="occupancy limiter experiment (see csim.h)")
     ap.add_argument("--wide", type=int, default=-1, help="256-column strips for the 3/4-step kernels")
     ap.add_argument("--fuse", type=int, default=-1,
                     help="time steps per HBM pass: -1 auto (deepest available), 0 off, 2..6")
@@ -147,6 +148,8 @@ def main():
                      ("prefetch", args.prefetch), ("overlap", 0 if args.no_overlap else 1),
                      ("fuse", args.fuse)):
         st.set_option(key, val)
+    if args.lds_bytes:
+        st.set_option("lds_bytes", args.lds_bytes)
     if args.wide >= 0:
         st.set_option("wide", args.wide)
     st.init_gaussian(1.0, 0.05, 0.5, 0.5)

@@ -1111,6 +1111,9 @@ int csim_stepper_set_option(csim_stepper* s, const char* key, long value) {
     } else if (k == "fuse") {
         CSIM_REQUIRE(value >= -1 && value <= MAX_FUSE, "fuse must be -1 (auto) or 0..6");
         s->fuse = static_cast<int>(value);
+    } else if (k == "lds_bytes") {
+        CSIM_REQUIRE(value >= 0 && value <= 65536, "lds_bytes must be 0..65536");
+        s->cfg.lds_bytes = static_cast<int>(value);
     } else if (k == "autotune") {
         s->autotune = value != 0;
         s->tuned = false;

@@ -63,6 +63,8 @@ struct SweepCfg {
     int variant = VAR_AUTO;
     int rows_per_chunk = 0;  // 0 = auto
     int tuned_rows = 0;      // auto mode: rows per chunk found by the stepper's on-device trial (0 = heuristic)
+    int lds_bytes = 0;       // dynamic LDS requested per workgroup of the fused sweep: an occupancy limiter
+                             // (41 KB -> 3 workgroups per CU instead of 4), the kernel never touches it
     int prefetch = 0;        // 0 = auto (rows kept in flight per wavefront)
     int xcd_swizzle = 1;
     int multistep = MS_OVERLAP;

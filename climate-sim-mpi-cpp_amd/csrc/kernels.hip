@@ -1578,7 +1578,7 @@ static hipError_t sweepO_div(const double* in, double* out, int nx, int ny, int 
     const int sw = cfg.xcd_swizzle;
     const int sign = (p.vx >= 0.0 ? 2 : 0) + (p.vy >= 0.0 ? 1 : 0);
 #define CSIM_LAUNCH_O(SXV, SYV)                                                                        \
-    hipLaunchKernelGGL((k_sweepO_dpp<DIV, T, SXV, SYV>), grid, block, 0, st, in, out, nx, ny, pitch, \
+    hipLaunchKernelGGL((k_sweepO_dpp<DIV, T, SXV, SYV>), grid, block, cfg.lds_bytes, st, in, out, nx, ny, pitch, \
                        nstrips, tl, sw, p, bc, fin)
     switch (sign) {
         case 3: CSIM_LAUNCH_O(1, 1); break;

@@ -68,3 +68,14 @@ def test_world2_gloo_oracle(case):
 def test_world4_gloo_oracle(case):
     rc, out = launch(4, "oracle", case)
     assert rc == 0 and "ok=True" in out, out[-2000:]
+
+
+@pytest.mark.parametrize("world", [6, 8])
+def test_world6_and_8_gloo_oracle(world):
+    """3x2 and 4x2 process grids (the 8-GPU decomposition of BASELINE configs[4]): ranks with both
+    x-neighbours, a y-neighbour and two diagonal peers"""
+    cases = cases_with(world)
+    assert cases
+    for case in cases:
+        rc, out = launch(world, "oracle", case)
+        assert rc == 0 and "ok=True" in out, out[-2000:]
