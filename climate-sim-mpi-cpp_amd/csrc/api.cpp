@@ -146,7 +146,11 @@ struct csim_stepper {
     bool widths128 = false;  // every tile width of the decomposition is a multiple of 128
     int faces_depth = 0;  // recv2[] holds the neighbours' faces of `cur` of this depth (0 = none)
     SweepCfg cfg;
-    int overlap = 1;
+    int overlap = 1;        // 0: exchange serial; 1: frame, then bulk hiding the exchange; 2: + frame of the next
+                            // pass concurrent with the bulk on its own stream (see pass_fused_concurrent)
+    bool frame_async = false;  // the last pass left frame work on s_frame that s_comp has not joined yet
+    int bulk_lds = 41984;      // mode 2: dynamic LDS per bulk workgroup = 3 instead of 4 workgroups per CU, so
+                               // that frame and RCCL workgroups always find a free slot
     int fuse = -1;  // time steps per HBM pass: -1 auto, 0/1 off, 2..4 depth (multi-rank runs cap at 2)
     int external = 0;  // halos are carried by the caller (csim_stepper_halo_pack/_unpack), not RCCL
     int profile = 0;
@@ -825,9 +829,15 @@ static int prof_end(csim_stepper* s) {
     return CSIM_OK;
 }
 
+static int join_frame(csim_stepper* s);
+
 // ONE reference step: exchange_halos + apply_boundary + fused sweep + swap
 static int pass_single(csim_stepper* s, const Phys& p, const GhostArgs& g) {
     const bool rccl = s->multi && !s->external;
+    {
+        int rc = join_frame(s);
+        if (rc) return rc;
+    }
     if (rccl) {
         if (!s->halo_fresh) {
             int rc = refresh_halos(s);  // on s_comp: ordered before the ghost fill
@@ -863,13 +873,68 @@ static int pass_single(csim_stepper* s, const Phys& p, const GhostArgs& g) {
 // computed first, their depth-next_T faces packed and sent on the comm stream, and the exchange
 // overlaps the rest of the sweep.
 static hipError_t launch_fused(csim_stepper* s, const Phys& p, const int kind[4], int T, int part,
-                               hipStream_t st, bool final_pass = false) {
-    if (s->cfg.multistep == MS_OVERLAP)
-        return launch_sweepO(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, s->cfg, kind, s->bc_value, T, part, st,
+                               hipStream_t st, bool final_pass = false, int lds_bytes = 0) {
+    if (s->cfg.multistep == MS_OVERLAP) {
+        SweepCfg cfg = s->cfg;
+        if (lds_bytes > 0) cfg.lds_bytes = lds_bytes;
+        return launch_sweepO(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, cfg, kind, s->bc_value, T, part, st,
                              final_pass ? s->fin : nullptr);
+    }
     if (T == 2)
         return launch_sweep2(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, s->cfg, kind, s->bc_value, part, st);
     return launch_sweepT(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, s->cfg, kind, s->bc_value, T, part, st);
+}
+
+// s_comp waits for the frame work a concurrent pass left on s_frame (no-op otherwise)
+static int join_frame(csim_stepper* s) {
+    if (s->frame_async) {
+        CSIM_HIP(hipStreamWaitEvent(s->s_comp, s->ev_edge2, 0));
+        s->frame_async = false;
+    }
+    return CSIM_OK;
+}
+
+// Steady-state pass of a multi-rank run in overlap mode 2.  What needs the neighbours' faces is
+// only the FRAME; the BULK of pass p depends on nothing but pass p-1.  So the bulk sweeps run back
+// to back on the compute stream, while unpack + ghost fill + frame of the same pass run on the
+// (high-priority) frame stream as soon as the exchange has delivered, concurrently with the bulk:
+//
+//   compute stream  record(B[p-1]) -> wait(F[p-1]) -> BULK[p]
+//   frame stream    wait(B[p-1]), wait(X[p-1]) -> unpack -> ghost fill -> FRAME[p] -> record(F[p])
+//   comm stream     wait(F[p]) -> pack faces of pass p+1 -> RCCL exchange -> record(X[p])
+//
+// The bulk is launched with a dynamic-LDS request that caps it at 3 workgroups per CU, so the frame
+// (and the RCCL kernel) always find wavefront slots instead of queueing behind ~100 us bulk tiles.
+// Requires the faces of depth T to be in flight already (the previous pass exchanged them).
+static int pass_fused_concurrent(csim_stepper* s, const Phys& p, int T, int next_T) {
+    int kind[4];
+    for (int k = 0; k < 4; ++k) kind[k] = s->phys[k] ? s->bc[k] : 3;
+    GhostArgs g = ghost_args(s);
+    for (int k = 0; k < 4; ++k) g.recv[k] = nullptr;
+    // everything enqueued on the compute stream so far: BULK[p-1] (or the whole previous pass)
+    CSIM_HIP(hipEventRecord(s->ev_ready, s->s_comp));
+    if (s->frame_async) CSIM_HIP(hipStreamWaitEvent(s->s_comp, s->ev_edge2, 0));  // FRAME[p-1]
+    int rc = prof_begin(s, T);
+    if (rc) return rc;
+    CSIM_HIP(launch_fused(s, p, kind, T, 2, s->s_comp, false, s->bulk_lds));
+    rc = prof_end(s);
+    if (rc) return rc;
+    CSIM_HIP(hipStreamWaitEvent(s->s_frame, s->ev_ready, 0));
+    CSIM_HIP(hipStreamWaitEvent(s->s_frame, s->ev_recv2, 0));  // X[p-1]: the faces this pass consumes
+    CSIM_HIP(launch_halo2_unpack(s->cur, s->nx, s->ny, s->pitch, T, s->recv2, s->s_frame));
+    CSIM_HIP(launch_ghost_fill(s->cur, s->nxt, s->nx, s->ny, s->pitch, g, s->s_frame, T));
+    CSIM_HIP(launch_fused(s, p, kind, T, 1, s->s_frame));
+    CSIM_HIP(hipEventRecord(s->ev_edge2, s->s_frame));
+    CSIM_HIP(hipStreamWaitEvent(s->s_comm, s->ev_edge2, 0));
+    CSIM_HIP(launch_halo2_pack(s->nxt, s->nx, s->ny, s->pitch, next_T, s->send2, s->s_comm));
+    rc = post_exchange2(s, next_T, s->s_comm);
+    if (rc) return rc;
+    CSIM_HIP(hipEventRecord(s->ev_recv2, s->s_comm));
+    s->faces_depth = next_T;
+    s->frame_async = true;
+    std::swap(s->cur, s->nxt);
+    s->halo_fresh = false;
+    return CSIM_OK;
 }
 
 // final_pass (overlapped-strip kernels only): the last pass of a run.  The kernel also emits the
@@ -878,6 +943,12 @@ static hipError_t launch_fused(csim_stepper* s, const Phys& p, const int kind[4]
 // last step (src/main.cpp:102-104 + src/diffusion.cpp:18-25) — without a trailing one-step pass.
 static int pass_fused(csim_stepper* s, const Phys& p, int T, int next_T, bool final_pass = false) {
     const bool rccl = s->multi && !s->external;
+    if (rccl && s->overlap == 2 && next_T >= 2 && s->faces_depth == T && s->cfg.multistep == MS_OVERLAP)
+        return pass_fused_concurrent(s, p, T, next_T);
+    {
+        int rc = join_frame(s);
+        if (rc) return rc;
+    }
     int kind[4];
     for (int k = 0; k < 4; ++k) kind[k] = s->phys[k] ? s->bc[k] : 3;
     GhostArgs g = ghost_args(s);
@@ -1055,7 +1126,7 @@ int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy,
         if (rc) return rc;
         remaining -= t;
     }
-    return CSIM_OK;
+    return join_frame(s);
 }
 
 int csim_stepper_sync(csim_stepper* s) {
@@ -1104,7 +1175,11 @@ int csim_stepper_set_option(csim_stepper* s, const char* key, long value) {
     } else if (k == "xcd_swizzle") {
         s->cfg.xcd_swizzle = value != 0;
     } else if (k == "overlap") {
-        s->overlap = value != 0;
+        CSIM_REQUIRE(value >= 0 && value <= 2, "overlap must be 0, 1 or 2");
+        s->overlap = static_cast<int>(value);
+    } else if (k == "bulk_lds") {
+        CSIM_REQUIRE(value >= 0 && value <= 65536, "bulk_lds must be 0..65536");
+        s->bulk_lds = static_cast<int>(value);
     } else if (k == "external_halo") {
         s->external = value != 0;
         s->halo_fresh = false;

@@ -160,7 +160,9 @@ int csim_stepper_sum(csim_stepper* s, double* out);
  *   "variant"        single-step kernel family: 0 auto, 1 dpp, 2 lds, 3 naive
  *   "rows_per_chunk" rows one wavefront marches per launch (0 auto), "prefetch" (single-step kernel)
  *   "xcd_swizzle"    0/1 XCD-aware block->tile map; "wide", "stagger": measured alternatives, off
- *   "overlap"        0/1 halo exchange on the comm stream concurrently with the sweep
+ *   "overlap"        0 serial exchange, 1 (default) frame tiles first and the exchange under the bulk sweep,
+ *                    2 additionally the next frame on its own stream beside the bulk ("bulk_lds": dynamic LDS
+ *                    per bulk workgroup as an occupancy cap, 0 = none)
  *   "external_halo"  0/1 the caller carries the faces (csim_stepper_halo_* / _faces_*)
  *   "profile"        0/1 HIP events around every sweep launch (csim_stepper_kernel_time)
  *   "autotune"       0/1 (default 1) with rows_per_chunk = 0: the first long run times the candidate

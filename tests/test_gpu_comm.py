@@ -52,7 +52,7 @@ def self_neighbor_decomp(csim, nx, ny, sides):
 # sides are {left,right} and/or {bottom,top}
 @pytest.mark.parametrize("sides,bc", [((1, 1, 1, 1), "dddd"), ((1, 1, 0, 0), "ddnd"),
                                       ((0, 0, 1, 1), "npdd"), ((1, 1, 0, 0), "ddpp")])
-@pytest.mark.parametrize("overlap", [1, 0])
+@pytest.mark.parametrize("overlap", [1, 0, 2])
 @pytest.mark.parametrize("shape", [(300, 170, 7), (256, 170, 9), (1024, 300, 12), (128, 2, 8),
                                    (1024, 300, 12, "wide")])
 def test_self_exchange_torus(csim, sides, bc, overlap, shape):
@@ -94,11 +94,13 @@ def test_torus_at_tile_scale_overlap_equals_serial_single_steps(csim):
     """a per-GPU-tile-sized torus (many strips x many chunks, so the frame / non-frame split and the
     8-direction deep faces are all in play): the overlapped 6-step schedule must reproduce the
     serial single-step schedule bit for bit."""
-    nx, ny, steps = 2048, 4096, 20
+    nx, ny, steps = 2048, 4096, 44
     d = self_neighbor_decomp(csim, nx, ny, (1, 1, 1, 1))
     ref = None
     for opts in [dict(overlap=0, fuse=0), dict(overlap=1, fuse=-1), dict(overlap=0, fuse=-1),
-                 dict(overlap=1, fuse=4, rows_per_chunk=64), dict(overlap=1, fuse=3, multistep=1)]:
+                 dict(overlap=1, fuse=4, rows_per_chunk=64), dict(overlap=1, fuse=3, multistep=1),
+                 dict(overlap=2, fuse=-1), dict(overlap=2, fuse=4, rows_per_chunk=64),
+                 dict(overlap=2, fuse=5, bulk_lds=0)]:
         st = csim.Stepper(d, 1.0, 1.0, csim.bc_codes("dddd"))
         st.comm_init(csim.comm_unique_id())
         for k, v in opts.items():

@@ -23,7 +23,7 @@ def main():
     csim.set_device(0)
     for sh in args.shape:
         nx, ny = (int(v) for v in sh.split("x"))
-        for mode in ("single", "torus-overlap", "torus-serial"):
+        for mode in ("single", "torus-overlap", "torus-concurrent", "torus-concurrent-nolds", "torus-serial"):
             d = csim.decomp_init(1, 0, nx, ny)
             if mode != "single":
                 for k in range(4):
@@ -31,7 +31,9 @@ def main():
             st = csim.Stepper(d, 1.0, 1.0, csim.bc_codes("dddd"))
             if mode != "single":
                 st.comm_init(csim.comm_unique_id())
-                st.set_option("overlap", 1 if mode == "torus-overlap" else 0)
+                st.set_option("overlap", {"torus-overlap": 1, "torus-serial": 0}.get(mode, 2))
+                if mode == "torus-concurrent-nolds":
+                    st.set_option("bulk_lds", 0)
             st.init_gaussian()
             t0 = time.perf_counter()
             while time.perf_counter() - t0 < 0.3:  # leave the idle clocks (and let the stepper tune its chunking)
