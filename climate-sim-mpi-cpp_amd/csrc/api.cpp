@@ -149,6 +149,8 @@ struct csim_stepper {
     int overlap = 1;        // 0: exchange serial; 1: frame, then bulk hiding the exchange; 2: + frame of the next
                             // pass concurrent with the bulk on its own stream (see pass_fused_concurrent)
     bool frame_async = false;  // the last pass left frame work on s_frame that s_comp has not joined yet
+    bool pre_unpacked = false; // the comm stream already unpacked the faces in recv2[] and filled the ghosts
+                               // for the next fused pass (ev_recv2 marks the end of that)
     int bulk_lds = 41984;      // mode 2: dynamic LDS per bulk workgroup = 3 instead of 4 workgroups per CU, so
                                // that frame and RCCL workgroups always find a free slot
     int fuse = -1;  // time steps per HBM pass: -1 auto, 0/1 off, 2..4 depth (multi-rank runs cap at 2)
@@ -953,6 +955,8 @@ static int pass_fused(csim_stepper* s, const Phys& p, int T, int next_T, bool fi
     for (int k = 0; k < 4; ++k) kind[k] = s->phys[k] ? s->bc[k] : 3;
     GhostArgs g = ghost_args(s);
     for (int k = 0; k < 4; ++k) g.recv[k] = nullptr;  // neighbour sides come from the deep faces
+    const bool prepared = s->multi && s->faces_depth == T && s->pre_unpacked;
+    s->pre_unpacked = false;
     if (s->multi) {
         if (s->faces_depth != T) {
             if (s->external)
@@ -963,9 +967,10 @@ static int pass_fused(csim_stepper* s, const Phys& p, int T, int next_T, bool fi
         } else if (rccl && s->overlap) {
             CSIM_HIP(hipStreamWaitEvent(s->s_comp, s->ev_recv2, 0));
         }
-        CSIM_HIP(launch_halo2_unpack(s->cur, s->nx, s->ny, s->pitch, T, s->recv2, s->s_comp));
+        if (!prepared) CSIM_HIP(launch_halo2_unpack(s->cur, s->nx, s->ny, s->pitch, T, s->recv2, s->s_comp));
     }
-    CSIM_HIP(launch_ghost_fill(s->cur, s->nxt, s->nx, s->ny, s->pitch, g, s->s_comp, s->multi ? T : 0));
+    if (!prepared)
+        CSIM_HIP(launch_ghost_fill(s->cur, s->nxt, s->nx, s->ny, s->pitch, g, s->s_comp, s->multi ? T : 0));
     int rc = prof_begin(s, T);
     if (rc) return rc;
     if (rccl && s->overlap && next_T >= 2) {
@@ -978,6 +983,15 @@ static int pass_fused(csim_stepper* s, const Phys& p, int T, int next_T, bool fi
         CSIM_HIP(launch_halo2_pack(s->nxt, s->nx, s->ny, s->pitch, next_T, s->send2, s->s_comm));
         rc = post_exchange2(s, next_T, s->s_comm);
         if (rc) return rc;
+        if (s->overlap == 1) {
+            // the comm stream goes on to prepare the next pass — unpack of the faces into the new
+            // field's halo cells, ghost fill of both buffers' rings — while the bulk is still
+            // sweeping: those cells are disjoint from everything the bulk reads or writes, and
+            // the frame cells the Neumann rule reads are final (the exchange waited for them)
+            CSIM_HIP(launch_halo2_unpack(s->nxt, s->nx, s->ny, s->pitch, next_T, s->recv2, s->s_comm));
+            CSIM_HIP(launch_ghost_fill(s->nxt, s->cur, s->nx, s->ny, s->pitch, g, s->s_comm, next_T));
+            s->pre_unpacked = true;
+        }
         CSIM_HIP(hipEventRecord(s->ev_recv2, s->s_comm));
         CSIM_HIP(launch_fused(s, p, kind, T, 2, s->s_comp));
         s->faces_depth = next_T;

@@ -1148,6 +1148,7 @@ __device__ __forceinline__ void ghost_extend_cell(double* __restrict__ f, int nx
 
 __global__ __launch_bounds__(256) void k_ghost_fill(double* __restrict__ a, double* __restrict__ b,
                                                     int nx, int ny, int pitch, GhostDev g) {
+    __builtin_amdgcn_s_setprio(3);  // short latency-critical kernel, usually sharing the SIMDs with a bulk sweep
     const int t = blockIdx.x * 256 + threadIdx.x;
     auto put = [&](size_t o, double v) {
         a[o] = v;
@@ -1278,6 +1279,7 @@ struct Halo2Ptrs {
 // ghost entries along, so that Periodic (never rewritten) ghosts reach the neighbour.
 __global__ __launch_bounds__(256) void k_halo2_pack(const double* __restrict__ f, int nx, int ny,
                                                     int pitch, int H, Halo2Ptrs s) {
+    __builtin_amdgcn_s_setprio(3);  // short latency-critical kernel, usually sharing the SIMDs with a bulk sweep
     const int t = blockIdx.x * 256 + threadIdx.x;
     auto ld = [&](int i, int j) { return f[static_cast<ptrdiff_t>(j) * pitch + (LPAD - 1) + i]; };
     if (t < H * (ny + 2)) {
@@ -1304,6 +1306,7 @@ __global__ __launch_bounds__(256) void k_halo2_pack(const double* __restrict__ f
 // next to a neighbour side the corner block of the diagonal rank supplies those cells.
 __global__ __launch_bounds__(256) void k_halo2_unpack(double* __restrict__ f, int nx, int ny, int pitch,
                                                       int H, Halo2Ptrs r) {
+    __builtin_amdgcn_s_setprio(3);  // short latency-critical kernel, usually sharing the SIMDs with a bulk sweep
     const int t = blockIdx.x * 256 + threadIdx.x;
     auto st = [&](int i, int j, double v) { f[static_cast<ptrdiff_t>(j) * pitch + (LPAD - 1) + i] = v; };
     if (t < H * (ny + 2)) {
