@@ -1112,7 +1112,7 @@ int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy,
     // The ghost ring left in the field must be exactly the reference's: the halos / boundary values
     // of the state before the LAST step (src/main.cpp:104 + src/diffusion.cpp:18-25).
     //  - overlapped-strip kernels: every pass is fused, the last one as `final_pass` (see
-    //    pass_fused); a run is never split so that a single step remains at the end;
+    //    pass_fused); a run of two or more steps never contains a single-step pass;
     //  - edge-lane-extras kernels (option multistep = 1): the last step is a one-step pass.
     const bool tailless = can_fuse && s->cfg.multistep == MS_OVERLAP;
     if (tailless && s->autotune && !s->tuned && s->cfg.rows_per_chunk == 0 && nsteps >= 4 * depth) {
@@ -1123,8 +1123,10 @@ int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy,
         if (!can_fuse) return 1;
         if (!tailless) return remaining >= 3 ? std::min(depth, remaining - 1) : 1;
         if (remaining < 2) return 1;
-        const int t = std::min(depth, remaining);
-        return (remaining - t == 1 && t > 2) ? t - 1 : t;
+        // as few passes as possible, of balanced depth (20 steps = 4 x 5 rather than 6 + 6 + 6 + 2:
+        // a shallow pass costs almost as much as a deep one)
+        const int npass = (remaining + depth - 1) / depth;
+        return (remaining + npass - 1) / npass;
     };
     int remaining = nsteps;
     while (remaining > 0) {
