@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--rows-per-chunk", type=int, default=0)
     ap.add_argument("--prefetch", type=int, default=0)
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--overlap-mode", type=int, default=-1,
+                    help="N > 1: -1 pick the fastest exchange schedule on this node, 0/1/2 force one")
     ap.add_argument("--lds-bytes", type=int, default=0, help="occupancy limiter experiment (see csim.h)")
     ap.add_argument("--wide", type=int, default=-1, help="256-column strips for the 3/4-step kernels")
     ap.add_argument("--fuse", type=int, default=-1,
@@ -93,12 +95,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test mode: ONE rank whose four neighbours are the rank itself, so that the whole N > 1 code path
+    # (RCCL communicator, deep faces in 8 directions, schedule selection) runs on a single GPU
+    self_torus = world == 1 and os.environ.get("CSIM_BENCH_SELF_TORUS") == "1"
+    multi = world > 1 or self_torus
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
 
     # CPU baseline first: it forks mpirun, which must happen before this process touches the GPU
     cpu = None
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not self_torus and not args.no_cpu_baseline:
         cores = min(16, os.cpu_count() or 1)
         cpu = cpu_baseline(cores)
 
@@ -112,14 +118,18 @@ def main():
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible (one rank per GPU)")
     csim.set_device(local_rank % max(ndev, 1))
 
-    if world > 1:
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     dec = csim.decomp_init(world, rank, args.nx, args.ny)
+    if self_torus:
+        for k in range(4):
+            dec.nbr[k] = 0
     st = csim.Stepper(dec, 1.0, 1.0, csim.bc_codes(BC), 0.0)
-    halo = "rccl" if world > 1 else "none"
-    if world > 1:
+    halo = "rccl" if multi else "none"
+    if multi:
         # RCCL communicator (unique id over the gloo control plane).  If it cannot be built on this
         # box the run falls back — on every rank — to host-staged faces over gloo, so that a scaling
         # number exists at all; the JSON line says which transport carried the halos.
@@ -166,7 +176,7 @@ def main():
 
     def global_sum():
         v = st.sum()
-        if world > 1:
+        if multi:
             t = torch.tensor([v], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             v = float(t.item())
@@ -179,7 +189,7 @@ def main():
 
     def barrier():
         st.sync()
-        if world > 1:
+        if multi:
             dist.barrier()
 
     # untimed: clock ramp (also triggers the stepper's one-off rows-per-chunk trial), then W warm-up steps
@@ -190,12 +200,48 @@ def main():
         st.sync()
         ramp_steps += 60
         done = time.perf_counter() - t_ramp >= args.ramp_seconds
-        if world > 1:  # every rank must take the same number of steps: decide together
+        if multi:  # every rank must take the same number of steps: decide together
             t = torch.tensor([1 if done else 0], dtype=torch.int64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             done = bool(t.item())
         if done:
             break
+    # N > 1 over RCCL: how the exchange is best hidden depends on what the RCCL kernel costs next
+    # to the sweep on this node, which cannot be known beforehand: time the schedules the stepper
+    # offers on a few passes each (untimed as far as `value` is concerned), keep the fastest on
+    # every rank, and report all of them (SURVEY §8d config 4 asks for overlapped and
+    # non-overlapped timings anyway)
+    exchange_modes = None
+    if multi and halo == "rccl" and not args.no_overlap and args.overlap_mode < 0:
+        cands = [("overlap-1 frame first, exchange under the bulk sweep", 1, None),
+                 ("overlap-0 exchange not overlapped", 0, None),
+                 ("overlap-2 frame stream beside the bulk, bulk capped at 3 workgroups/CU", 2, 41984),
+                 ("overlap-2 frame stream beside the bulk", 2, 0)]
+        exchange_modes = {}
+        k2 = 240
+        for name, ov, lds in cands:
+            st.set_option("overlap", ov)
+            if lds is not None:
+                st.set_option("bulk_lds", lds)
+            advance(24)
+            barrier()
+            t0 = time.perf_counter()
+            advance(k2)
+            st.sync()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            exchange_modes[name] = float(t.item()) / k2 * 1e3  # ms per step, max over ranks: same on all
+        best = min(exchange_modes, key=exchange_modes.get)
+        if exchange_modes[best] > 0.98 * exchange_modes[cands[0][0]]:
+            best = cands[0][0]  # within noise of the default schedule: keep the default
+        for name, ov, lds in cands:
+            if name == best:
+                st.set_option("overlap", ov)
+                if lds is not None:
+                    st.set_option("bulk_lds", lds)
+        exchange_modes["chosen"] = best
+    elif multi and args.overlap_mode >= 0:
+        st.set_option("overlap", args.overlap_mode)
     advance(args.warmup)
     barrier()
     st.set_option("profile", 1)
@@ -205,34 +251,13 @@ def main():
     st.sync()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    if world > 1:
+    if multi:
         dist.barrier()
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    # N > 1 over RCCL: the same steps once more with the exchange NOT overlapped (SURVEY §8d config 4
-    # asks for both); untimed as far as `value` is concerned
-    serial_ms = None
-    if world > 1 and halo == "rccl" and not args.no_overlap:
-        kinds_main = {t: st.kernel_time(t) for t in (1, 2, 3, 4, 5, 6)}
-        st.set_option("profile", 0)
-        st.set_option("overlap", 0)
-        k2 = min(args.steps, 300)
-        advance(12)
-        barrier()
-        t0 = time.perf_counter()
-        advance(k2)
-        st.sync()
-        dt_serial = time.perf_counter() - t0
-        dist.barrier()
-        t = torch.tensor([dt_serial], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        serial_ms = float(t.item()) / k2 * 1e3
-        st.set_option("overlap", 1)
-    else:
-        kinds_main = None
     # dominant kernel = the one that advanced most of the timed steps
-    kinds = kinds_main or {t: st.kernel_time(t) for t in (1, 2, 3, 4, 5, 6)}
+    kinds = {t: st.kernel_time(t) for t in (1, 2, 3, 4, 5, 6)}
     steps_per_launch = max(kinds, key=lambda t: t * kinds[t][1])
     kern_ms, launches = kinds[steps_per_launch]
     mn, mx = st.minmax()
@@ -242,7 +267,7 @@ def main():
     if mass_drift > 1e-9 and rank == 0:
         sys.stderr.write(f"[bench] WARNING: total mass drifted by {mass_drift:.3e} (halo exchange broken?)\n")
     st.close()
-    if world > 1:
+    if multi:
         km = torch.tensor([kern_ms], dtype=torch.float64)
         dist.all_reduce(km, op=dist.ReduceOp.MAX)
         kern_ms = float(km.item())
@@ -284,9 +309,10 @@ def main():
                 "workload": f"{args.nx}x{args.ny} fp64 gaussian hotspot, D={PHYS['D']} "
                             f"v=({PHYS['vx']},{PHYS['vy']}) dt={dt} dx=dy=1, all-Dirichlet(0), "
                             f"decomp {dec.dims[0]}x{dec.dims[1]} (local {dec.nx_local}x{dec.ny_local}), "
-                            f"halo overlap {'off' if args.no_overlap else 'on'}",
+                            f"halo overlap {'off' if args.no_overlap else 'on'}"
+                            + (" — TEST MODE: one rank linked to itself in all 8 directions" if self_torus else ""),
                 "halo_transport": halo,
-                "ms_per_step_exchange_not_overlapped": serial_ms,
+                "exchange_schedules_ms_per_step": exchange_modes,
                 "hbm_gbs_whole_job": cells * args.steps * BYTES_PER_CELL / elapsed / 1e9,
                 "field_min_max_after_run": [mn, mx],
                 "relative_mass_drift": mass_drift,
