@@ -1,0 +1,45 @@
+"""bench.py end to end on one GPU: the JSON contract of the N = 1 line (small grid, no CPU baseline)
+and — through the self-linked torus test mode — the whole N > 1 code path: RCCL communicator, deep
+faces in 8 directions, the trial of the exchange schedules, mass conservation across the seams."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(extra, env=None):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--nx", "1536", "--ny", "1024", "--steps", "37",
+           "--warmup", "7", "--ramp-seconds", "0.02", "--no-cpu-baseline"] + extra
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, **(env or {})))
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract_single_gpu():
+    r = run_bench([])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in r, key
+    assert r["n_gpus"] == 1 and r["steps"] == 37 and r["warmup"] == 7 and r["dtype"] == "f64"
+    assert r["unit"] == "Mcell-updates/s" and r["higher_is_better"] is True and r["vs_baseline"] is None
+    assert abs(r["value"] - 1536 * 1024 * 37 / (r["ms_per_step"] * 37 * 1e-3) / 1e6) < 1e-6 * r["value"]
+    rf = r["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert r["config"]["relative_mass_drift"] < 1e-9
+
+
+def test_bench_multi_rank_path_on_self_linked_torus():
+    r = run_bench([], env={"CSIM_BENCH_SELF_TORUS": "1"})
+    cfg = r["config"]
+    assert cfg["halo_transport"] == "rccl"
+    sched = cfg["exchange_schedules_ms_per_step"]
+    assert sched["chosen"] in sched and len(sched) == 5
+    assert cfg["relative_mass_drift"] < 1e-9  # a lost or misplaced face would leak mass at the seams
