@@ -61,9 +61,8 @@ int main(int argc, char** argv) {
 
     const int stride = 128 - 4 * ((T + 1) / 2);
     const int nstrips = (nx + stride - 1) / stride;
-    const int nwgx = (nstrips + 3) / 4;
     const int nchunks = (ny + ry - 1) / ry;
-    const int nblocks = nwgx * nchunks;
+    const int nblocks = (nstrips * nchunks + 3) / 4;
     const size_t nwaves = static_cast<size_t>(nblocks) * 4;
     unsigned long long* d_tr;
     CK(hipMalloc(&d_tr, nwaves * 3 * sizeof(unsigned long long)));
@@ -159,7 +158,9 @@ int main(int argc, char** argv) {
                     const int per = nblocks >> 3, rem = nblocks & 7, xcd = bidx & 7, q = bidx >> 3;
                     lin = xcd < rem ? xcd * (per + 1) + q : rem * (per + 1) + (xcd - rem) * per + q;
                 }
-                const int wgx = lin % nwgx, chunk = lin / nwgx, strip = wgx * 4 + wv;
+                const int tile = lin * 4 + wv;
+                if (tile >= nstrips * nchunks) continue;
+                const int strip = tile % nstrips, chunk = tile / nstrips;
                 const int jb = chunk * ry + 1, je = std::min(jb + ry - 1, ny), g0 = strip * stride - TPv;
                 const bool edge = strip == 0 || g0 + 128 > nx || jb - (T - 1) < 1 || je + (T - 1) > ny;
                 (edge ? de : di).push_back(d);
