@@ -326,6 +326,11 @@ def main():
                 "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS,
                 "traffic": traffic,
+                # what really moved through HBM per second (PMC bytes / live kernel time): the kernel
+                # advances 6 time steps per pass, so `achieved` (algorithmic) exceeds the peak while
+                # the real traffic stays below it
+                "traffic_gbs": (traffic / (kern_avg_ms * 1e-3) / 1e9) if traffic else None,
+                "traffic_frac_of_peak": (traffic / (kern_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                 "kernel": ("k_sweep_dpp" if steps_per_launch == 1 else f"k_sweepO_dpp<T={steps_per_launch}>") +
                           f" (fused copy+diffusion+advection, {steps_per_launch} time step(s) per HBM pass)",
                 "kernel_avg_ms": kern_avg_ms,
