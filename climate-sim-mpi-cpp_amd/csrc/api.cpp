@@ -1033,9 +1033,16 @@ static int tune_rows(csim_stepper* s, const Phys& p, int T) {
     if (cand.size() < 2) return CSIM_OK;
     int kind[4];
     for (int k = 0; k < 4; ++k) kind[k] = s->phys[k] ? s->bc[k] : 3;
-    hipEvent_t e0, e1;
-    CSIM_HIP(hipEventCreate(&e0));
-    CSIM_HIP(hipEventCreate(&e1));
+    struct EventPair {  // destroyed on every return path
+        hipEvent_t a = nullptr, b = nullptr;
+        ~EventPair() {
+            if (a) (void)hipEventDestroy(a);
+            if (b) (void)hipEventDestroy(b);
+        }
+    } ev;
+    CSIM_HIP(hipEventCreate(&ev.a));
+    CSIM_HIP(hipEventCreate(&ev.b));
+    const hipEvent_t e0 = ev.a, e1 = ev.b;
     CSIM_HIP(hipStreamSynchronize(s->s_comp));
     SweepCfg cfg = s->cfg;
     auto trial = [&](int ry, float* ms) -> int {
@@ -1066,8 +1073,6 @@ static int tune_rows(csim_stepper* s, const Phys& p, int T) {
     for (size_t c = 1; c < cand.size(); ++c)
         if (best[c] < best[arg]) arg = c;
     s->cfg.tuned_rows = cand[arg];
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     return CSIM_OK;
 }
 
