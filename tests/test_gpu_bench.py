@@ -43,3 +43,28 @@ def test_bench_multi_rank_path_on_self_linked_torus():
     sched = cfg["exchange_schedules_ms_per_step"]
     assert sched["chosen"] in sched and len(sched) == 5
     assert cfg["relative_mass_drift"] < 1e-9  # a lost or misplaced face would leak mass at the seams
+
+
+def test_bench_two_ranks_host_staged_fallback():
+    """two bench ranks sharing this GPU with CSIM_BENCH_HALO=gloo: the fall-back transport bench.py
+    uses when the RCCL communicator cannot be built (RCCL refuses two ranks on one device)"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = str(s.getsockname()[1])
+    s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=port, CSIM_BENCH_HALO="gloo", OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--nx", "1536",
+                                       "--ny", "1024", "--steps", "37", "--warmup", "7", "--ramp-seconds", "0.02"],
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
+    lines = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["scaling"] == "strong"
+    assert r["config"]["halo_transport"].startswith("gloo")
+    assert r["config"]["relative_mass_drift"] < 1e-9
