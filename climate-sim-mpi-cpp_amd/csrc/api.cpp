@@ -155,7 +155,7 @@ struct csim_stepper {
                                // for the next fused pass (ev_recv2 marks the end of that)
     int bulk_lds = 41984;      // mode 2: dynamic LDS per bulk workgroup = 3 instead of 4 workgroups per CU, so
                                // that frame and RCCL workgroups always find a free slot
-    int fuse = -1;  // time steps per HBM pass: -1 auto, 0/1 off, 2..4 depth (multi-rank runs cap at 2)
+    int fuse = -1;  // time steps per HBM pass: -1 auto (deepest available), 0/1 off, 2..6 depth
     int external = 0;  // halos are carried by the caller (csim_stepper_halo_pack/_unpack), not RCCL
     int profile = 0;
     int autotune = 1;     // pick rows_per_chunk (when 0 = auto) by timing trial launches on this GPU
@@ -886,10 +886,10 @@ static int pass_single(csim_stepper* s, const Phys& p, const GhostArgs& g) {
     return CSIM_OK;
 }
 
-// T = 2..4 reference steps in one HBM pass.  Several ranks: faces of depth T (8 directions) are
+// T = 2..6 reference steps in one HBM pass.  Several ranks: faces of depth T (8 directions) are
 // staged in recv2[]; when the next pass is fused too (with `next_T` steps), the frame tiles are
-// computed first, their depth-next_T faces packed and sent on the comm stream, and the exchange
-// overlaps the rest of the sweep.
+// computed first and the comm stream packs and exchanges their depth-next_T faces while the bulk
+// of the sweep is still running.
 static hipError_t launch_fused(csim_stepper* s, const Phys& p, const int kind[4], int T, int part,
                                hipStream_t st, bool final_pass = false, int lds_bytes = 0) {
     if (s->cfg.multistep == MS_OVERLAP) {

@@ -93,7 +93,7 @@ hipError_t launch_sweepO(const double* in, double* out, int nx, int ny, int pitc
                          hipStream_t st, double* const fin_lines[4] = nullptr);
 constexpr int MAX_FUSE = 6;       // deepest temporal blocking (overlapped-strip kernel; the extras kernels stop at 4)
 constexpr int GHOST_EXTRA = 5;    // device-only ghost layers beyond the reference's one (= MAX_FUSE-1)
-// faces of depth H = 2..4 (8 directions: L R B T BL BR TL TR; nullptr = no neighbour there);
+// faces of depth H = 2..6 (8 directions: L R B T BL BR TL TR; nullptr = no neighbour there);
 // sizes H*(ny+2) (L,R), H*(nx+2) (B,T), H*H (corners)
 hipError_t launch_halo2_pack(const double* f, int nx, int ny, int pitch, int depth,
                              double* const send[8], hipStream_t st);
