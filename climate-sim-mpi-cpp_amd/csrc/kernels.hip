@@ -18,6 +18,7 @@
 // src/diffusion.cpp:9-16, src/advection.cpp:13-33) and this file is compiled with
 // -ffp-contract=off, so every kernel is bit-identical to the reference CPU path.
 #include <algorithm>
+#include <type_traits>
 
 #include "internal.hpp"
 
@@ -647,13 +648,20 @@ __device__ __forceinline__ void sweepO_march(const double* __restrict__ in, doub
 #pragma unroll
         for (int q = 0; q < 3; ++q) L[l][q] = make_double2(0.0, 0.0);
 
-    for (int k0 = 0; k0 < niter; k0 += 6) {
+    // One group = six iterations.  Level l has nothing valid to produce before iteration 2 (l - 1)
+    // (its first needed row, jb - (T - l), comes out exactly then), so the first two groups are
+    // separate copies of the body in which the not-yet-started levels are left out at compile time:
+    // 30 of the 6 (ry + 10) level-rows of a chunk at T = 6.  (The edge body keeps the single generic
+    // copy: it is rare and its code is three times the size.)
+    auto group = [&](auto gtag, int k0) {
+        constexpr int G = decltype(gtag)::value;
 #pragma unroll
         for (int u = 0; u < 6; ++u) {
             {
                 const int r = r_first + k0 + u;
 #pragma unroll
                 for (int l = 1; l <= T; ++l) {
+                    if (G < 2 && 6 * G + u < 2 * (l - 1)) continue;  // compile-time: level not started yet
                     const int rho = r - l + 1;
                     const double2 s = (l == 1) ? L0[u % 6] : L[l - 1][(u + 1) % 3];
                     const double2 c = (l == 1) ? L0[(u + 1) % 6] : L[l - 1][(u + 2) % 3];
@@ -726,6 +734,13 @@ __device__ __forceinline__ void sweepO_march(const double* __restrict__ in, doub
                 L0[u % 6] = load(min(r + 5, last_row));  // row r-1 is dead: its slot takes row r+5
             }
         }
+    };
+    if (EDGE) {
+        for (int k0 = 0; k0 < niter; k0 += 6) group(std::integral_constant<int, 2>{}, k0);
+    } else {
+        group(std::integral_constant<int, 0>{}, 0);
+        if (niter > 6) group(std::integral_constant<int, 1>{}, 6);
+        for (int k0 = 12; k0 < niter; k0 += 6) group(std::integral_constant<int, 2>{}, k0);
     }
 }
 
