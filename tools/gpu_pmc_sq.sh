@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp
 for shape in ${SHAPES:-16384x16384}; do
-  timeout -k 10 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_sq_$shape -- python3 $R/tools/sweep_variants.py --shape $shape --steps 25 --rounds 1 --variants 1 --ry ${RY:-122} --pf 2 --fuse ${FUSE:-6} > $R/gpurun_out/pmc_sq_$shape.log 2>&1 || exit 1
+  timeout -k 10 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_sq_$shape -- python3 $R/tools/sweep_variants.py --shape $shape --steps 24 --rounds 1 --variants 1 --ry ${RY:-122} --pf 2 --fuse ${FUSE:-6} > $R/gpurun_out/pmc_sq_$shape.log 2>&1 || exit 1
 done
 cd $R
 python3 - <<'PY'
