@@ -37,11 +37,11 @@ def test_bench_line_contract_single_gpu():
 
 
 def test_bench_multi_rank_path_on_self_linked_torus():
-    r = run_bench([], env={"CSIM_BENCH_SELF_TORUS": "1"})
+    r = run_bench([], env={"CSIM_BENCH_SELF_TORUS": "1", "CSIM_BENCH_TRY_OVERLAP2": "1"})
     cfg = r["config"]
     assert cfg["halo_transport"] == "rccl"
     sched = cfg["exchange_schedules_ms_per_step"]
-    assert sched["chosen"] in sched and len(sched) == 5
+    assert sched["chosen"] in sched and len(sched) == 5  # overlap 1, 0 and the two opt-in overlap-2 variants
     assert cfg["relative_mass_drift"] < 1e-9  # a lost or misplaced face would leak mass at the seams
 
 
