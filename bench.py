@@ -246,7 +246,9 @@ def main():
         st.set_option("overlap", args.overlap_mode)
     advance(args.warmup)
     barrier()
-    st.set_option("profile", 1)
+    # HIP events around every sweep launch at N = 1; around every 8th pass at N > 1, where the two
+    # event records per pass would cost ~10 % of a 170 us pass
+    st.set_option("profile", 8 if multi else 1)
     st.reset_timers()
     t0 = time.perf_counter()
     advance(args.steps)

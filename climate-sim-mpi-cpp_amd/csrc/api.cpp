@@ -157,7 +157,9 @@ struct csim_stepper {
                                // that frame and RCCL workgroups always find a free slot
     int fuse = -1;  // time steps per HBM pass: -1 auto (deepest available), 0/1 off, 2..6 depth
     int external = 0;  // halos are carried by the caller (csim_stepper_halo_pack/_unpack), not RCCL
-    int profile = 0;
+    int profile = 0;        // 0 off, k >= 1: HIP events around every k-th pass
+    bool prof_active = false;
+    unsigned long prof_counter = 0;
     int autotune = 1;     // pick rows_per_chunk (when 0 = auto) by timing trial launches on this GPU
     bool tuned = false;
     std::vector<hipEvent_t> ev_pool;  // start/stop pairs around sweep launches
@@ -821,7 +823,10 @@ static int prof_fold(csim_stepper* s) {
 
 static int prof_begin(csim_stepper* s, int steps) {
     constexpr size_t POOL = 2048;
-    if (!s->profile) return CSIM_OK;
+    // profile = k > 1: only every k-th pass is bracketed (two event records cost a few microseconds
+    // of stream time each, which shows on the ~170 us passes of a small multi-rank tile)
+    s->prof_active = s->profile > 0 && (s->prof_counter++ % s->profile) == 0;
+    if (!s->prof_active) return CSIM_OK;
     if (s->ev_used + 2 > POOL) {
         int rc = prof_fold(s);
         if (rc) return rc;
@@ -838,7 +843,8 @@ static int prof_begin(csim_stepper* s, int steps) {
 }
 
 static int prof_end(csim_stepper* s) {
-    if (!s->profile) return CSIM_OK;
+    if (!s->prof_active) return CSIM_OK;
+    s->prof_active = false;
     CSIM_HIP(hipEventRecord(s->ev_pool[s->ev_used + 1], s->s_comp));
     s->ev_used += 2;
     return CSIM_OK;
@@ -1236,7 +1242,9 @@ int csim_stepper_set_option(csim_stepper* s, const char* key, long value) {
     } else if (k == "tuned_rows") {  // read back through csim_stepper_get_option
         return fail(CSIM_ERR_ARG, "tuned_rows is read-only");
     } else if (k == "profile") {
-        s->profile = value != 0;
+        CSIM_REQUIRE(value >= 0 && value <= 1024, "profile must be 0..1024");
+        s->profile = static_cast<int>(value);
+        s->prof_counter = 0;
     } else {
         return fail(CSIM_ERR_ARG, "unknown option: " + k);
     }

@@ -164,7 +164,8 @@ int csim_stepper_sum(csim_stepper* s, double* out);
  *                    2 additionally the next frame on its own stream beside the bulk ("bulk_lds": dynamic LDS
  *                    per bulk workgroup as an occupancy cap, 0 = none)
  *   "external_halo"  0/1 the caller carries the faces (csim_stepper_halo_* / _faces_*)
- *   "profile"        0/1 HIP events around every sweep launch (csim_stepper_kernel_time)
+ *   "profile"        0 off, k >= 1: HIP events around the sweep launch(es) of every k-th pass
+ *                    (csim_stepper_kernel_time)
  *   "autotune"       0/1 (default 1) with rows_per_chunk = 0: the first long run times the candidate
  *                    chunk heights on this GPU (trial launches that do not advance the field) and keeps
  *                    the fastest; "tuned_rows" (read-only) reports it */
