@@ -87,7 +87,6 @@ def main():
     ap.add_argument("--overlap-mode", type=int, default=-1,
                     help="N > 1: -1 pick the fastest exchange schedule on this node, 0/1/2 force one")
     ap.add_argument("--lds-bytes", type=int, default=0, help="occupancy limiter experiment (see csim.h)")
-    ap.add_argument("--wide", type=int, default=-1, help="256-column strips for the 3/4-step kernels")
     ap.add_argument("--fuse", type=int, default=-1,
                     help="time steps per HBM pass: -1 auto (deepest available), 0 off, 2..6")
     args = ap.parse_args()
@@ -160,8 +159,6 @@ def main():
         st.set_option(key, val)
     if args.lds_bytes:
         st.set_option("lds_bytes", args.lds_bytes)
-    if args.wide >= 0:
-        st.set_option("wide", args.wide)
     st.init_gaussian(1.0, 0.05, 0.5, 0.5)
     dt = min(PHYS["dt"], csim.safe_dt(1.0, 1.0, PHYS["vx"], PHYS["vy"], PHYS["D"]))
 

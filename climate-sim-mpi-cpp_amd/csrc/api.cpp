@@ -125,6 +125,7 @@ struct csim_stepper {
     ncclComm_t comm = nullptr;
     bool multi = false;       // has at least one neighbour
     bool halo_fresh = false;  // recv[] holds the neighbours' edge lines of `cur`
+    bool edge_async = false;  // ... and the exchange that delivers them was posted on s_comm (ev_recv marks its end)
     // depth-2 faces for two-steps-per-pass on several ranks; directions L R B T BL BR TL TR
     int nbr8[8]{-1, -1, -1, -1, -1, -1, -1, -1};
     size_t cap2[8]{0, 0, 0, 0, 0, 0, 0, 0};  // staging capacity (faces of depth MAX_FUSE)
@@ -143,7 +144,6 @@ struct csim_stepper {
     hipEvent_t ev_snap_src = nullptr, ev_snap_copied = nullptr;
     bool snap_pending = false;
     int fuse_cap = 1;     // deepest pass every rank of the decomposition can run (same on all ranks)
-    bool widths128 = false;  // every tile width of the decomposition is a multiple of 128
     int faces_depth = 0;  // recv2[] holds the neighbours' faces of `cur` of this depth (0 = none)
     SweepCfg cfg;
     int overlap = 1;        // 0: exchange serial; 1: frame, then bulk hiding the exchange; 2: + frame of the next
@@ -438,10 +438,7 @@ int csim_stepper_create(const csim_decomp* dec, double dx, double dy, const int 
     {
         const int px = dec->dims[0] > 0 ? dec->dims[0] : 1, py = dec->dims[1] > 0 ? dec->dims[1] : 1;
         const int gx = dec->nx_global > 0 ? dec->nx_global : s->nx, gy = dec->ny_global > 0 ? dec->ny_global : s->ny;
-        const int bx = gx / px, rx = gx % px, by = gy / py;
-        // (the edge-lane-extras kernels additionally need every tile width to be a multiple of 128)
-        s->widths128 = s->multi ? (bx > 0 && bx % WAVE_COLS == 0 && (bx + rx) % WAVE_COLS == 0)
-                                : (s->nx % WAVE_COLS == 0);
+        const int bx = gx / px, by = gy / py;
         const int min_tile = s->multi ? std::min(bx, by) : MAX_FUSE;
         s->fuse_cap = std::max(1, std::min(MAX_FUSE, min_tile));
     }
@@ -586,13 +583,12 @@ int csim_stepper_download_interior(csim_stepper* s, double* host) {
 int csim_stepper_snapshot_begin(csim_stepper* s) {
     CSIM_REQUIRE(s, "null stepper");
     const size_t bytes = sizeof(double) * static_cast<size_t>(s->nx) * s->ny;
-    if (!s->s_io) {
-        CSIM_HIP(hipStreamCreateWithFlags(&s->s_io, hipStreamNonBlocking));
-        CSIM_HIP(hipEventCreateWithFlags(&s->ev_snap_src, hipEventDisableTiming));
-        CSIM_HIP(hipEventCreateWithFlags(&s->ev_snap_copied, hipEventDisableTiming));
-        CSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s->snap_d), bytes));
-        CSIM_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->snap_h), bytes, hipHostMallocDefault));
-    }
+    // each piece is created once; a failed allocation is reported and retried by the next call
+    if (!s->s_io) CSIM_HIP(hipStreamCreateWithFlags(&s->s_io, hipStreamNonBlocking));
+    if (!s->ev_snap_src) CSIM_HIP(hipEventCreateWithFlags(&s->ev_snap_src, hipEventDisableTiming));
+    if (!s->ev_snap_copied) CSIM_HIP(hipEventCreateWithFlags(&s->ev_snap_copied, hipEventDisableTiming));
+    if (!s->snap_d) CSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s->snap_d), bytes));
+    if (!s->snap_h) CSIM_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->snap_h), bytes, hipHostMallocDefault));
     if (s->snap_pending) CSIM_HIP(hipStreamSynchronize(s->s_io));  // previous snapshot still in flight
     CSIM_HIP(hipEventRecord(s->ev_snap_src, s->s_comp));
     CSIM_HIP(hipStreamWaitEvent(s->s_io, s->ev_snap_src, 0));
@@ -681,6 +677,7 @@ static int refresh_halos(csim_stepper* s) {
     int rc = post_exchange(s, s->s_comp);
     if (rc) return rc;
     s->halo_fresh = true;
+    s->edge_async = false;
     return CSIM_OK;
 }
 
@@ -741,15 +738,13 @@ static bool depth_ok(const csim_stepper* s, int depth) {
     return depth >= 2 && depth <= MAX_FUSE && depth <= s->nx && depth <= s->ny;
 }
 
+static int fused_depth(const csim_stepper* s);
+
 // deepest fused pass this stepper can run (1 = single steps only); identical on every rank of a
 // decomposition, so external-transport callers can schedule their passes the way run() does
 int csim_stepper_fuse_limit(const csim_stepper* s, int* depth) {
     CSIM_REQUIRE(s && depth, "null argument");
-    int d = std::min(s->fuse < 0 ? MAX_FUSE : s->fuse, s->fuse_cap);
-    if (s->cfg.multistep == MS_EXTRAS) d = std::min(d, 4);
-    const bool dpp_family = s->cfg.variant == VAR_AUTO || s->cfg.variant == VAR_DPP;
-    const bool ok = d >= 2 && dpp_family && (s->cfg.multistep == MS_OVERLAP || s->widths128);
-    *depth = ok ? d : 1;
+    *depth = fused_depth(s);
     return CSIM_OK;
 }
 
@@ -863,9 +858,11 @@ static int pass_single(csim_stepper* s, const Phys& p, const GhostArgs& g) {
         if (!s->halo_fresh) {
             int rc = refresh_halos(s);  // on s_comp: ordered before the ghost fill
             if (rc) return rc;
-        } else if (s->overlap) {
+        } else if (s->edge_async) {
+            // whatever "overlap" says NOW: the exchange in flight was posted on the comm stream
             CSIM_HIP(hipStreamWaitEvent(s->s_comp, s->ev_recv, 0));
         }
+        s->edge_async = false;
     }
     // exchange_halos (unpack) + apply_boundary, mirrored into the partner buffer
     if (!s->ring_ok) {
@@ -880,6 +877,7 @@ static int pass_single(csim_stepper* s, const Phys& p, const GhostArgs& g) {
         int rc = post_exchange(s, s->s_comm);
         if (rc) return rc;
         CSIM_HIP(hipEventRecord(s->ev_recv, s->s_comm));
+        s->edge_async = true;
     }
     int rc = prof_begin(s, 1);
     if (rc) return rc;
@@ -898,15 +896,10 @@ static int pass_single(csim_stepper* s, const Phys& p, const GhostArgs& g) {
 // of the sweep is still running.
 static hipError_t launch_fused(csim_stepper* s, const Phys& p, const int kind[4], int T, int part,
                                hipStream_t st, bool final_pass = false, int lds_bytes = 0) {
-    if (s->cfg.multistep == MS_OVERLAP) {
-        SweepCfg cfg = s->cfg;
-        if (lds_bytes > 0) cfg.lds_bytes = lds_bytes;
-        return launch_sweepO(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, cfg, kind, s->bc_value, T, part, st,
-                             final_pass ? s->fin : nullptr);
-    }
-    if (T == 2)
-        return launch_sweep2(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, s->cfg, kind, s->bc_value, part, st);
-    return launch_sweepT(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, s->cfg, kind, s->bc_value, T, part, st);
+    SweepCfg cfg = s->cfg;
+    if (lds_bytes > 0) cfg.lds_bytes = lds_bytes;
+    return launch_sweepO(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, cfg, kind, s->bc_value, T, part, st,
+                         final_pass ? s->fin : nullptr);
 }
 
 // s_comp waits for the frame work a concurrent pass left on s_frame (no-op otherwise)
@@ -967,7 +960,7 @@ static int pass_fused_concurrent(csim_stepper* s, const Phys& p, int T, int next
 // last step (src/main.cpp:102-104 + src/diffusion.cpp:18-25) — without a trailing one-step pass.
 static int pass_fused(csim_stepper* s, const Phys& p, int T, int next_T, bool final_pass = false) {
     const bool rccl = s->multi && !s->external;
-    if (rccl && s->overlap == 2 && next_T >= 2 && s->faces_depth == T && s->cfg.multistep == MS_OVERLAP)
+    if (rccl && s->overlap == 2 && next_T >= 2 && s->faces_depth == T)
         return pass_fused_concurrent(s, p, T, next_T);
     {
         int rc = join_frame(s);
@@ -1103,30 +1096,26 @@ static int tune_rows(csim_stepper* s, const Phys& p, int T) {
 
 // deepest fused pass of this stepper with the current options (1 = single steps only)
 static int fused_depth(const csim_stepper* s) {
-    int depth = std::min(s->fuse < 0 ? MAX_FUSE : s->fuse, s->fuse_cap);
-    if (s->cfg.multistep == MS_EXTRAS) depth = std::min(depth, 4);
+    const int depth = std::min(s->fuse < 0 ? MAX_FUSE : s->fuse, s->fuse_cap);
     const bool dpp_family = s->cfg.variant == VAR_AUTO || s->cfg.variant == VAR_DPP;
-    const bool can_fuse = depth >= 2 && dpp_family && (s->cfg.multistep == MS_OVERLAP || s->widths128);
-    return can_fuse ? depth : 1;
+    return depth >= 2 && dpp_family ? depth : 1;
 }
 
 // the one-off trial of csim_stepper_run's first long call, on request (e.g. before a timed loop)
 int csim_stepper_tune(csim_stepper* s, double D, double dt, double vx, double vy) {
     CSIM_REQUIRE(s, "null stepper");
     const int depth = fused_depth(s);
-    if (depth < 2 || s->cfg.multistep != MS_OVERLAP || s->tuned || s->cfg.rows_per_chunk != 0) return CSIM_OK;
+    if (depth < 2 || s->tuned || s->cfg.rows_per_chunk != 0) return CSIM_OK;
     return tune_rows(s, make_phys(s->dx, s->dy, D, dt, vx, vy), depth);
 }
 
 int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy, int nsteps) {
     CSIM_REQUIRE(s, "null stepper");
     CSIM_REQUIRE(nsteps >= 0, "nsteps must be >= 0");
-    // Up to MAX_FUSE steps per HBM pass where possible: width a multiple of 128 and, across
-    // ranks, a tile at least as large as the face depth.
-    int depth = std::min(s->fuse < 0 ? MAX_FUSE : s->fuse, s->fuse_cap);
-    if (s->cfg.multistep == MS_EXTRAS) depth = std::min(depth, 4);
-    const bool dpp_family = s->cfg.variant == VAR_AUTO || s->cfg.variant == VAR_DPP;
-    const bool can_fuse = depth >= 2 && dpp_family && (s->cfg.multistep == MS_OVERLAP || s->widths128);
+    // Up to MAX_FUSE steps per HBM pass where possible (across ranks: a tile at least as large as
+    // the face depth).
+    const int depth = fused_depth(s);
+    const bool can_fuse = depth >= 2;
     if (s->multi && s->external) {
         // the caller carries the faces: one step (depth-1 faces) or one fused pass per call
         if (nsteps == 1 && !s->halo_fresh)
@@ -1141,18 +1130,14 @@ int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy,
     if (s->multi && s->external && nsteps >= 2) return pass_fused(s, p, nsteps, 0);
     // The ghost ring left in the field must be exactly the reference's: the halos / boundary values
     // of the state before the LAST step (src/main.cpp:104 + src/diffusion.cpp:18-25).
-    //  - overlapped-strip kernels: every pass is fused, the last one as `final_pass` (see
-    //    pass_fused); a run of two or more steps never contains a single-step pass;
-    //  - edge-lane-extras kernels (option multistep = 1): the last step is a one-step pass.
-    const bool tailless = can_fuse && s->cfg.multistep == MS_OVERLAP;
-    if (tailless && s->autotune && !s->tuned && s->cfg.rows_per_chunk == 0 && nsteps >= 4 * depth) {
+    // Every pass is fused, the last one as `final_pass` (see pass_fused); a run of two or more
+    // steps never contains a single-step pass.
+    if (can_fuse && s->autotune && !s->tuned && s->cfg.rows_per_chunk == 0 && nsteps >= 4 * depth) {
         int rc = tune_rows(s, p, depth);
         if (rc) return rc;
     }
     auto pass_len = [&](int remaining) {
-        if (!can_fuse) return 1;
-        if (!tailless) return remaining >= 3 ? std::min(depth, remaining - 1) : 1;
-        if (remaining < 2) return 1;
+        if (!can_fuse || remaining < 2) return 1;
         // as few passes as possible, of balanced depth (20 steps = 4 x 5 rather than 6 + 6 + 6 + 2:
         // a shallow pass costs almost as much as a deep one)
         const int npass = (remaining + depth - 1) / depth;
@@ -1165,7 +1150,7 @@ int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy,
         if (t >= 2) {
             const int nt = pass_len(remaining - t);
             const bool last = remaining == t;
-            rc = pass_fused(s, p, t, (!last && nt >= 2) ? nt : 0, tailless && last);
+            rc = pass_fused(s, p, t, (!last && nt >= 2) ? nt : 0, last);
         } else {
             rc = pass_single(s, p, g);
         }
@@ -1210,14 +1195,6 @@ int csim_stepper_set_option(csim_stepper* s, const char* key, long value) {
     } else if (k == "prefetch") {
         CSIM_REQUIRE(value >= 0 && value <= 8, "prefetch must be 0..8");
         s->cfg.prefetch = static_cast<int>(value);
-    } else if (k == "multistep") {
-        CSIM_REQUIRE(value == MS_OVERLAP || value == MS_EXTRAS, "multistep must be 0 (overlap) or 1 (extras)");
-        s->cfg.multistep = static_cast<int>(value);
-    } else if (k == "stagger") {
-        CSIM_REQUIRE(value >= 0 && value <= 4096, "stagger must be 0..4096");
-        s->cfg.stagger = static_cast<int>(value);
-    } else if (k == "wide") {
-        s->cfg.wide = value != 0;
     } else if (k == "xcd_swizzle") {
         s->cfg.xcd_swizzle = value != 0;
     } else if (k == "overlap") {
@@ -1258,7 +1235,6 @@ int csim_stepper_get_option(const csim_stepper* s, const char* key, long* value)
     else if (k == "rows_per_chunk") *value = s->cfg.rows_per_chunk;
     else if (k == "tuned_rows") *value = s->cfg.tuned_rows;
     else if (k == "prefetch") *value = s->cfg.prefetch;
-    else if (k == "multistep") *value = s->cfg.multistep;
     else if (k == "xcd_swizzle") *value = s->cfg.xcd_swizzle;
     else if (k == "overlap") *value = s->overlap;
     else if (k == "external_halo") *value = s->external;

@@ -56,8 +56,6 @@ Phys make_phys(double dx, double dy, double D, double dt, double vx, double vy);
 
 // kernel variants of the fused sweep (option "variant")
 enum { VAR_AUTO = 0, VAR_DPP = 1, VAR_LDS = 2, VAR_NAIVE = 3 };
-// multi-step kernel families (option "multistep"): overlapped strips (default) or edge-lane extras
-enum { MS_OVERLAP = 0, MS_EXTRAS = 1 };
 
 struct SweepCfg {
     int variant = VAR_AUTO;
@@ -67,31 +65,20 @@ struct SweepCfg {
                              // (41 KB -> 3 workgroups per CU instead of 4), the kernel never touches it
     int prefetch = 0;        // 0 = auto (rows kept in flight per wavefront)
     int xcd_swizzle = 1;
-    int multistep = MS_OVERLAP;
-    int stagger = 0;         // T >= 3 sweeps: start offset between co-resident workgroups (x 64 cycles)
-    int wide = 0;            // T >= 3 sweeps: 256-column strips per wavefront (needs nx % 256 == 0)
 };
 
 // ---- kernel launchers (kernels.hip) --------------------------------------------------------
 // All pointers are device pointers in the padded layout above.
 hipError_t launch_sweep(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
                         const SweepCfg& cfg, hipStream_t st);
-// two fused time steps per pass; kind[s] = CSIM_BC_* on physical sides, 3 on neighbour sides
-bool sweep2_supported(int nx, const SweepCfg& cfg);
-// part: 0 = every tile, 1 = frame tiles only, 2 = all but the frame tiles
-hipError_t launch_sweep2(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
-                         const SweepCfg& cfg, const int kind[4], double value, int part,
-                         hipStream_t st);
-// T = 3 or 4 time steps per pass (same kind[] / part conventions as launch_sweep2)
-hipError_t launch_sweepT(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
-                         const SweepCfg& cfg, const int kind[4], double value, int T, int part,
-                         hipStream_t st);
+// T = 2..6 fused time steps per pass (overlapped strips).  kind[s] = CSIM_BC_* on physical sides, 3 on
+// neighbour sides; part: 0 = every tile, 1 = frame tiles only, 2 = all but the frame tiles.
 // fin_lines (last pass of a run, all four or nullptr): per side the level T-1 line the final ghost
 // fill needs — see FinLines in kernels.hip
 hipError_t launch_sweepO(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
                          const SweepCfg& cfg, const int kind[4], double value, int T, int part,
                          hipStream_t st, double* const fin_lines[4] = nullptr);
-constexpr int MAX_FUSE = 6;       // deepest temporal blocking (overlapped-strip kernel; the extras kernels stop at 4)
+constexpr int MAX_FUSE = 6;       // deepest temporal blocking
 constexpr int GHOST_EXTRA = 5;    // device-only ghost layers beyond the reference's one (= MAX_FUSE-1)
 // faces of depth H = 2..6 (8 directions: L R B T BL BR TL TR; nullptr = no neighbour there);
 // sizes H*(ny+2) (L,R), H*(nx+2) (B,T), H*H (corners)

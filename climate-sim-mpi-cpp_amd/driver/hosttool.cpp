@@ -6,6 +6,8 @@
 //                 reference-named API open_netcdf_parallel / write_field_netcdf / close
 //   csim_hosttool nc-read in.nc var step out.bin
 //   csim_hosttool nc-attrs in.nc
+#include <sys/resource.h>
+
 #include <cstdio>
 #include <fstream>
 #include <iostream>
@@ -39,7 +41,7 @@ static std::string jstr(const std::string& s) {
 
 int main(int argc, char** argv) {
     try {
-        if (argc < 2) throw std::runtime_error("usage: csim_hosttool print-config|nc-write|nc-read|nc-attrs ...");
+        if (argc < 2) throw std::runtime_error("usage: csim_hosttool print-config|nc-write|nc-read|nc-read-window|nc-attrs ...");
         const std::string cmd = argv[1];
         std::vector<std::string> args(argv + 2, argv + argc);
         if (cmd == "print-config") {
@@ -82,6 +84,22 @@ int main(int argc, char** argv) {
             std::ofstream out(args[3], std::ios::binary);
             out.write(reinterpret_cast<const char*>(v.data()), static_cast<std::streamsize>(v.size() * 8));
             std::printf("%d %d\n", ny, nx);
+        } else if (cmd == "nc-read-window") {
+            // one rank's block of an IC file, as the driver loads it: into the interior of a (wy+2) x (wx+2)
+            // array with a ghost ring; prints the file's extent and by how many KiB the read raised this process's peak RSS
+            if (args.size() < 8) throw std::runtime_error("nc-read-window in.nc var step y0 x0 wy wx out.bin");
+            const int y0 = std::stoi(args[3]), x0 = std::stoi(args[4]), wy = std::stoi(args[5]), wx = std::stoi(args[6]);
+            int ny = 0, nx = 0;
+            std::vector<double> v(static_cast<size_t>(wy + 2) * (wx + 2), -7.0);
+            struct rusage ru0 {};
+            getrusage(RUSAGE_SELF, &ru0);  // peak so far: the process image with its shared libraries
+            read_netcdf_window(args[0], args[1], std::stoi(args[2]), y0, x0, wy, wx, &v[static_cast<size_t>(wx + 2) + 1],
+                               static_cast<size_t>(wx + 2), ny, nx);
+            std::ofstream out(args[7], std::ios::binary);
+            out.write(reinterpret_cast<const char*>(v.data()), static_cast<std::streamsize>(v.size() * 8));
+            struct rusage ru {};
+            getrusage(RUSAGE_SELF, &ru);
+            std::printf("%d %d %ld\n", ny, nx, ru.ru_maxrss - ru0.ru_maxrss);
         } else if (cmd == "nc-attrs") {
             for (auto& kv : read_netcdf_attrs(args.at(0))) std::printf("%s=%s\n", kv.first.c_str(), kv.second.c_str());
         } else {

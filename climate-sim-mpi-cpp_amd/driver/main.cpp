@@ -55,14 +55,15 @@ void initial_condition(const Decomp2D& dec, Field& u, const SimConfig& cfg) {
             throw std::runtime_error("Unknown IC preset: " + cfg.ic.preset);
         }
     } else if (cfg.ic.mode == "file") {  // extension: classic NetCDF (y,x) or (time,y,x) double
+        // every rank reads only its own block (rows y_offset.., columns x_offset..) row by row into
+        // the interior of its Field: per-rank start/count like the reference's writer, src/io.cpp:402-418
+        const std::string var = cfg.ic.var.empty() ? "u" : cfg.ic.var;
         int ny = 0, nx = 0;
-        std::vector<double> g;
-        read_netcdf_2d(cfg.ic.path, cfg.ic.var.empty() ? "u" : cfg.ic.var, 0, ny, nx, g);
+        netcdf_dims_2d(cfg.ic.path, var, ny, nx);
         if (ny != cfg.ny || nx != cfg.nx) throw std::runtime_error("IC file grid does not match nx/ny");
-        for (int j = 0; j < u.ny_local; ++j)
-            for (int i = 0; i < u.nx_local; ++i)
-                u.data[static_cast<size_t>(j + 1) * u.nx_total() + 1 + i] =
-                    g[static_cast<size_t>(dec.y_offset + j) * nx + dec.x_offset + i];
+        read_netcdf_window(cfg.ic.path, var, 0, dec.y_offset, dec.x_offset, u.ny_local, u.nx_local,
+                           &u.data[static_cast<size_t>(u.nx_total()) + 1], static_cast<size_t>(u.nx_total()),
+                           ny, nx);
     } else {
         throw std::runtime_error("Unknown IC mode: " + cfg.ic.mode);
     }
@@ -117,6 +118,7 @@ int main(int argc, char** argv) {
 
     int ndev = 0;
     climate::check(csim_device_count(&ndev));
+    if (ndev <= 0) throw std::runtime_error("no HIP device visible (check HIP_VISIBLE_DEVICES): this driver has no CPU path");
     const char* lr = std::getenv("LOCAL_RANK");
     climate::check(csim_set_device(lr ? std::atoi(lr) % ndev : world_rank % ndev));
 

@@ -325,9 +325,9 @@ std::vector<std::pair<std::string, std::string>> read_netcdf_attrs(const std::st
     return parse(filename).gatts;
 }
 
-void read_netcdf_2d(const std::string& filename, const std::string& var, int step, int& ny, int& nx,
-                    std::vector<double>& out) {
-    const Parsed P = parse(filename);
+namespace {
+// locate record `step` of a double variable with dims ([time,] y, x): file offset of its first element
+int64_t locate_2d(const Parsed& P, const std::string& var, int step, int& ny, int& nx) {
     auto it = P.vars.find(var);
     if (it == P.vars.end()) throw std::runtime_error("netcdf: no variable " + var);
     const VarInfo& v = it->second;
@@ -338,23 +338,66 @@ void read_netcdf_2d(const std::string& filename, const std::string& var, int ste
     ny = static_cast<int>(P.dims[static_cast<size_t>(v.dimids[nd - 2])].second);
     nx = static_cast<int>(P.dims[static_cast<size_t>(v.dimids[nd - 1])].second);
     if (rec && (step < 0 || step >= P.numrecs)) throw std::runtime_error("netcdf: record out of range");
-    const int64_t off = v.begin + (rec ? static_cast<int64_t>(step) * P.recsize : 0);
-    out.resize(static_cast<size_t>(ny) * nx);
-    const int fd = ::open(filename.c_str(), O_RDONLY);
-    if (fd < 0) throw std::runtime_error("netcdf: cannot open " + filename);
+    return v.begin + (rec ? static_cast<int64_t>(step) * P.recsize : 0);
+}
+
+void pread_doubles(int fd, double* dst, size_t count, int64_t off) {
     size_t got = 0;
-    const size_t want = out.size() * 8;
+    const size_t want = count * 8;
     while (got < want) {
-        const ssize_t k = ::pread(fd, reinterpret_cast<char*>(out.data()) + got, want - got, off + static_cast<int64_t>(got));
+        const ssize_t k = ::pread(fd, reinterpret_cast<char*>(dst) + got, want - got, off + static_cast<int64_t>(got));
         if (k <= 0) break;
         got += static_cast<size_t>(k);
     }
-    ::close(fd);
     if (got != want) throw std::runtime_error("netcdf: short read");
-    for (double& d : out) {
+    for (size_t k = 0; k < count; ++k) {
         uint64_t bits;
-        std::memcpy(&bits, &d, 8);
+        std::memcpy(&bits, &dst[k], 8);
         bits = bswap(bits);
-        std::memcpy(&d, &bits, 8);
+        std::memcpy(&dst[k], &bits, 8);
     }
+}
+}  // namespace
+
+void read_netcdf_2d(const std::string& filename, const std::string& var, int step, int& ny, int& nx,
+                    std::vector<double>& out) {
+    const Parsed P = parse(filename);
+    const int64_t off = locate_2d(P, var, step, ny, nx);
+    out.resize(static_cast<size_t>(ny) * nx);
+    const int fd = ::open(filename.c_str(), O_RDONLY);
+    if (fd < 0) throw std::runtime_error("netcdf: cannot open " + filename);
+    try {
+        pread_doubles(fd, out.data(), out.size(), off);
+    } catch (...) {
+        ::close(fd);
+        throw;
+    }
+    ::close(fd);
+}
+
+// Per-rank window of the same record: rows y0 .. y0+wy-1, columns x0 .. x0+wx-1, one pread per row
+// straight into `dst` (row stride `dst_stride` doubles).  Nothing of global size is allocated — the
+// counterpart of the per-rank start/count of the reference's writer (src/io.cpp:402-418).
+void read_netcdf_window(const std::string& filename, const std::string& var, int step, int y0, int x0,
+                        int wy, int wx, double* dst, size_t dst_stride, int& ny, int& nx) {
+    const Parsed P = parse(filename);
+    const int64_t off = locate_2d(P, var, step, ny, nx);
+    if (y0 < 0 || x0 < 0 || wy < 0 || wx < 0 || y0 + wy > ny || x0 + wx > nx)
+        throw std::runtime_error("netcdf: window outside the variable");
+    const int fd = ::open(filename.c_str(), O_RDONLY);
+    if (fd < 0) throw std::runtime_error("netcdf: cannot open " + filename);
+    try {
+        for (int j = 0; j < wy; ++j)
+            pread_doubles(fd, dst + static_cast<size_t>(j) * dst_stride, static_cast<size_t>(wx),
+                          off + (static_cast<int64_t>(y0 + j) * nx + x0) * 8);
+    } catch (...) {
+        ::close(fd);
+        throw;
+    }
+    ::close(fd);
+}
+
+void netcdf_dims_2d(const std::string& filename, const std::string& var, int& ny, int& nx) {
+    const Parsed P = parse(filename);
+    (void)locate_2d(P, var, 0, ny, nx);
 }

@@ -25,5 +25,13 @@ void close_netcdf_parallel(int ncid);
 // reads record `step` of variable `var` (double, dims [time,]y,x) from a classic CDF-1/2/5 file
 void read_netcdf_2d(const std::string& filename, const std::string& var, int step, int& ny, int& nx,
                     std::vector<double>& out);
+// a window of that record (rows y0.., columns x0.., wy x wx) read row by row straight into `dst`
+// (row stride dst_stride doubles): what each rank of a decomposed run loads of an IC file — no
+// buffer of global size anywhere (per-rank start/count like reference src/io.cpp:402-418);
+// ny/nx return the variable's full extent
+void read_netcdf_window(const std::string& filename, const std::string& var, int step, int y0, int x0,
+                        int wy, int wx, double* dst, size_t dst_stride, int& ny, int& nx);
+// extent of the variable without reading data
+void netcdf_dims_2d(const std::string& filename, const std::string& var, int& ny, int& nx);
 // the global text attributes of such a file, in file order
 std::vector<std::pair<std::string, std::string>> read_netcdf_attrs(const std::string& filename);

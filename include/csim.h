@@ -156,10 +156,9 @@ int csim_stepper_minmax(csim_stepper* s, double out_min_max[2]);
 int csim_stepper_sum(csim_stepper* s, double* out);
 /* tuning / measurement knobs; unknown keys give CSIM_ERR_ARG.  Results never depend on them.
  *   "fuse"           time steps per HBM pass: -1 auto (deepest the decomposition allows), 0/1 off, 2..6
- *   "multistep"      multi-step kernel family: 0 overlapped strips (default), 1 edge-lane extras (<= 4 steps)
  *   "variant"        single-step kernel family: 0 auto, 1 dpp, 2 lds, 3 naive
  *   "rows_per_chunk" rows one wavefront marches per launch (0 auto), "prefetch" (single-step kernel)
- *   "xcd_swizzle"    0/1 XCD-aware block->tile map; "wide", "stagger": measured alternatives, off
+ *   "xcd_swizzle"    0/1 XCD-aware block->tile map
  *   "overlap"        0 serial exchange, 1 (default) frame tiles first and the exchange under the bulk sweep,
  *                    2 additionally the next frame on its own stream beside the bulk ("bulk_lds": dynamic LDS
  *                    per bulk workgroup as an occupancy cap, 0 = none)

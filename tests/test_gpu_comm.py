@@ -53,13 +53,10 @@ def self_neighbor_decomp(csim, nx, ny, sides):
 @pytest.mark.parametrize("sides,bc", [((1, 1, 1, 1), "dddd"), ((1, 1, 0, 0), "ddnd"),
                                       ((0, 0, 1, 1), "npdd"), ((1, 1, 0, 0), "ddpp")])
 @pytest.mark.parametrize("overlap", [1, 0, 2])
-@pytest.mark.parametrize("shape", [(300, 170, 7), (256, 170, 9), (1024, 300, 12), (128, 2, 8),
-                                   (1024, 300, 12, "wide")])
+@pytest.mark.parametrize("shape", [(300, 170, 7), (256, 170, 9), (1024, 300, 12), (128, 2, 8)])
 def test_self_exchange_torus(csim, sides, bc, overlap, shape):
-    wide = len(shape) == 4
-    shape = shape[:3]
-    # widths that are multiples of 128 take the fused two-step passes: depth-2 faces and corner
-    # blocks in 8 directions, frame tiles first, exchange overlapped with the remaining tiles
+    # fused passes across "ranks": deep faces and corner blocks in 8 directions, frame tiles first,
+    # exchange overlapped with the remaining tiles
     nx, ny, steps = shape
     D, vx, vy, dt = 0.05, 0.5, -0.25, 0.1
     rng = np.random.default_rng(17)
@@ -71,8 +68,6 @@ def test_self_exchange_torus(csim, sides, bc, overlap, shape):
     st = csim.Stepper(self_neighbor_decomp(csim, nx, ny, sides), 1.0, 1.0, codes)
     st.comm_init(csim.comm_unique_id())
     st.set_option("overlap", overlap)
-    st.set_option("wide", 1 if wide else 0)
-    st.set_option("multistep", 1 if wide else 0)
     st.upload(u0)
     st.run(D, dt, vx, vy, 3)
     st.run(D, dt, vx, vy, steps - 3)
@@ -98,7 +93,7 @@ def test_torus_at_tile_scale_overlap_equals_serial_single_steps(csim):
     d = self_neighbor_decomp(csim, nx, ny, (1, 1, 1, 1))
     ref = None
     for opts in [dict(overlap=0, fuse=0), dict(overlap=1, fuse=-1), dict(overlap=0, fuse=-1),
-                 dict(overlap=1, fuse=4, rows_per_chunk=64), dict(overlap=1, fuse=3, multistep=1),
+                 dict(overlap=1, fuse=4, rows_per_chunk=64), dict(overlap=1, fuse=3),
                  dict(overlap=2, fuse=-1), dict(overlap=2, fuse=4, rows_per_chunk=64),
                  dict(overlap=2, fuse=5, bulk_lds=0)]:
         st = csim.Stepper(d, 1.0, 1.0, csim.bc_codes("dddd"))

@@ -95,6 +95,30 @@ def test_driver_ic_from_netcdf_file(tmp_path):
     assert np.array_equal(rec[0], z["u0"]) and np.array_equal(rec[1], z["u_final"])
 
 
+@pytest.mark.skipif(not os.path.exists(MPIRUN), reason="no mpirun in this image")
+@pytest.mark.parametrize("case,np_ranks,dims", [("run_fused_256x48", 4, "2x2"), ("run_mixed_bc_random", 2, "2x1")])
+def test_driver_mpi_ranks_window_the_netcdf_ic(tmp_path, case, np_ranks, dims):
+    """config 5's shape at test size: a decomposed run whose ranks each read ONLY their block of the IC
+    file (read_netcdf_window: per-rank start/count like reference src/io.cpp:402-418), then step with
+    MPI faces; the snapshot records must equal the golden run from the same initial field."""
+    exe = os.path.join(DRV, "climate_sim_hip_mpi")
+    if not os.path.exists(exe):
+        pytest.skip("MPI flavour not built")
+    z, m = golden(case)
+    raw = tmp_path / "ic.bin"
+    np.ascontiguousarray(z["u0"]).tofile(raw)
+    ic = tmp_path / "ic.nc"
+    subprocess.run([os.path.join(DRV, "csim_hosttool"), "nc-write", str(ic), str(raw), "1",
+                    f"--nx={m['nx']}", f"--ny={m['ny']}"], check=True)
+    m2 = dict(m, sigma_frac=0.05)
+    out, h = run_driver(tmp_path, "climate_sim_hip_mpi", m2, m["steps"] + 1, m["steps"],
+                        launcher=(MPIRUN, "-np", str(np_ranks)),
+                        extra=("--halo=mpi", "--ic.mode=file", f"--ic.path={ic}"))
+    rec = records(h, m)
+    assert np.array_equal(rec[0], z["u0"]) and np.array_equal(rec[1], z["u_final"])
+    assert f"dims={dims}" in out
+
+
 def test_driver_rejects_bad_ic(tmp_path):
     """reference tests/simulation/integration/integration_boundary_error.cpp: a bad IC preset gives
     a non-zero exit and no output file."""

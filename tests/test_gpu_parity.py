@@ -23,7 +23,7 @@ VARIANT_CFGS = [dict(variant=1, prefetch=1), dict(variant=1, prefetch=2), dict(v
                 dict(variant=1, prefetch=8, rows_per_chunk=7), dict(variant=1, rows_per_chunk=1),
                 dict(variant=1, xcd_swizzle=0), dict(variant=2), dict(variant=2, rows_per_chunk=5),
                 dict(variant=3), dict(fuse=0), dict(fuse=2), dict(fuse=3), dict(fuse=4),
-                dict(fuse=4, rows_per_chunk=3), dict(fuse=3, rows_per_chunk=1), dict(fuse=4, multistep=1),
+                dict(fuse=4, rows_per_chunk=3), dict(fuse=3, rows_per_chunk=1),
                 dict(fuse=5), dict(fuse=6), dict(fuse=6, rows_per_chunk=2), dict(fuse=5, rows_per_chunk=1)]
 
 
@@ -185,7 +185,7 @@ SEEDED = [
     (127, 1, 1.0, 1.0, 0.1, 0.4, 0.4, 0.1, "dddd", 5),
     (1, 300, 1.0, 1.0, 0.1, 0.4, -0.4, 0.1, "nndd", 5),
     (2049, 515, 1.0, 1.0, 0.05, 0.5, 0.25, 0.1, "dddd", 8),     # config 3 physics, ragged strips
-    # widths that are multiples of 128 take the two-steps-per-pass kernel by default
+    # widths that are multiples of 128: whole strips
     (128, 5, 1.0, 1.0, 0.1, 0.3, -0.2, 0.1, "dnpd", 9),
     (256, 1, 1.0, 1.0, 0.1, -0.3, 0.2, 0.1, "nnnn", 8),
     (128, 2, 1.0, 1.0, 0.1, 0.3, 0.2, 0.1, "pppp", 7),
@@ -194,7 +194,7 @@ SEEDED = [
     (640, 67, 1.0, 1.0, 0.05, 0.5, -0.25, 0.1, "ndnd", 11),
     (256, 40, 0.5, 0.25, 0.01, 0.3, -0.2, 0.05, "dnnd", 9),     # exact-reciprocal path, fused
     (128, 30, 0.7, 1.3, 0.08, -0.6, 0.9, 0.1, "npdn", 7),       # IEEE-division path, fused
-    (512, 70, 1.0, 1.0, 0.1, -0.3, 0.2, 0.1, "dnpn", 10),       # 2 wide (256-column) strips
+    (512, 70, 1.0, 1.0, 0.1, -0.3, 0.2, 0.1, "dnpn", 10),
     (768, 9, 0.5, 0.5, 0.02, 0.2, 0.3, 0.1, "nnpp", 9),
 ]
 
@@ -214,12 +214,9 @@ def test_seeded_random_vs_oracle_bit_exact(csim, case):
                  dict(fuse=2, rows_per_chunk=64, prefetch=4), dict(fuse=2, xcd_swizzle=0),
                  dict(fuse=3), dict(fuse=3, rows_per_chunk=2, prefetch=4), dict(fuse=3, rows_per_chunk=1),
                  dict(fuse=4), dict(fuse=4, rows_per_chunk=5, prefetch=4), dict(fuse=4, xcd_swizzle=0),
-                 dict(fuse=4, rows_per_chunk=1), dict(fuse=4, wide=1), dict(fuse=3, wide=1, rows_per_chunk=3),
-                 dict(fuse=4, wide=1, rows_per_chunk=1), dict(fuse=3, wide=1, xcd_swizzle=0),
+                 dict(fuse=4, rows_per_chunk=1),
                  dict(fuse=5), dict(fuse=6), dict(fuse=6, rows_per_chunk=3), dict(fuse=5, rows_per_chunk=1),
-                 dict(fuse=6, xcd_swizzle=0, rows_per_chunk=7),
-                 dict(fuse=2, multistep=1), dict(fuse=3, multistep=1, rows_per_chunk=2),
-                 dict(fuse=4, multistep=1), dict(fuse=4, multistep=1, rows_per_chunk=5)]:
+                 dict(fuse=6, xcd_swizzle=0, rows_per_chunk=7)]:
         got = run_gpu(csim, u0, dx, dy, D, vx, vy, dt, csim.bc_codes(bc), steps, opts)
         assert np.array_equal(got, want), (opts, float(np.abs(got - want).max()))
     got = run_gpu(csim, u0, dx, dy, D, vx, vy, dt, csim.bc_codes(bc), steps, None,
@@ -375,11 +372,9 @@ def _window_check(csim, nx, ny, D, vx, vy, dt, bc, steps, opts, nwin, seed):
     return got
 
 
-@pytest.mark.parametrize("fuse,wide,ms", [(-1, 0, 0), (2, 0, 0), (3, 0, 0), (4, 0, 0), (5, 0, 0), (4, 0, 1),
-                                          (4, 1, 1), (3, 1, 1)])
-def test_full_size_config2_4096_diffusion_periodic(csim, fuse, wide, ms):
-    got = _window_check(csim, 4096, 4096, 1.0, 0.0, 0.0, 0.1, "pppp", 14,
-                        dict(fuse=fuse, wide=wide, multistep=ms), 12, 42)
+@pytest.mark.parametrize("fuse", [-1, 2, 3, 4, 5])
+def test_full_size_config2_4096_diffusion_periodic(csim, fuse):
+    got = _window_check(csim, 4096, 4096, 1.0, 0.0, 0.0, 0.1, "pppp", 14, dict(fuse=fuse), 12, 42)
     assert np.isfinite(got).all()
 
 
@@ -406,8 +401,7 @@ def test_long_run_all_schedules_agree_bitwise(csim):
     outs = {}
     sums = {}
     for name, opts in [("fuse6", dict(fuse=6)), ("fuse4", dict(fuse=4)), ("fuse2", dict(fuse=2)),
-                       ("fuse0", dict(fuse=0)), ("lds", dict(fuse=0, variant=2)),
-                       ("extras4", dict(fuse=4, multistep=1))]:
+                       ("fuse0", dict(fuse=0)), ("lds", dict(fuse=0, variant=2))]:
         st = csim.Stepper.single(nx, ny, 1.0, 1.0, csim.bc_codes("nnnn"))
         for k, v in opts.items():
             st.set_option(k, v)

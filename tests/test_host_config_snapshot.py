@@ -184,3 +184,30 @@ def test_cdf2_flavour_is_readable_by_scipy(tmp_path):
         assert f.variables["u"].shape == (nrec, ny, nx)
         assert np.array_equal(f.variables["u"][:], data)
         assert f.description == b"climate-sim-mpi-cpp" and f.grid == b"6 x 4"
+
+
+def test_windowed_ic_read_never_holds_the_global_array(tmp_path):
+    """ic.mode=file on a decomposed run: every rank reads only rows y_offset.. / columns x_offset.. of
+    the record (per-rank start/count like reference src/io.cpp:402-418).  The read must not
+    raise the process's peak RSS by anything near the size of the global array."""
+    nx, ny = 2048, 1536                     # 25 MB record
+    rng = np.random.default_rng(5)
+    data = rng.standard_normal((2, ny, nx))
+    raw = tmp_path / "raw.bin"
+    data.tofile(raw)
+    out = tmp_path / "ic.nc"
+    tool("nc-write", str(out), str(raw), "2", f"--nx={nx}", f"--ny={ny}")
+    for (y0, x0, wy, wx) in [(0, 0, 3, 5), (700, 1000, 96, 130), (ny - 64, nx - 100, 64, 100), (0, 0, 1, nx)]:
+        back = tmp_path / "win.bin"
+        r = tool("nc-read-window", str(out), "u", "1", str(y0), str(x0), str(wy), str(wx), str(back))
+        got_ny, got_nx, rss_kib = (int(v) for v in r.stdout.split())
+        assert (got_ny, got_nx) == (ny, nx)
+        w = np.fromfile(back).reshape(wy + 2, wx + 2)
+        assert np.array_equal(w[1:-1, 1:-1], data[1, y0:y0 + wy, x0:x0 + wx])
+        ring = np.ones(w.shape, bool)
+        ring[1:-1, 1:-1] = False
+        assert (w[ring] == -7.0).all()           # nothing outside the interior was touched
+        assert rss_kib * 1024 < nx * ny * 8 // 8, rss_kib   # growth of the peak RSS: the 25 MB record was never resident
+    r = subprocess.run([TOOL, "nc-read-window", str(out), "u", "0", "10", "10", str(ny), "4", str(tmp_path / "x.bin")],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "window outside" in r.stderr

@@ -23,9 +23,6 @@ def main():
     ap.add_argument("--pf", type=int, nargs="+", default=[1, 2, 4, 8])
     ap.add_argument("--swz", type=int, nargs="+", default=[1])
     ap.add_argument("--fuse", type=int, nargs="+", default=[0, 2, 3, 4])
-    ap.add_argument("--wide", type=int, nargs="+", default=[0])
-    ap.add_argument("--stagger", type=int, nargs="+", default=[0])
-    ap.add_argument("--multistep", type=int, nargs="+", default=[0])
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     csim = load_package()
@@ -40,11 +37,8 @@ def main():
         cfgs = []
         for v in args.variants:
             if v in (0, 1):
-                cfgs += [dict(variant=v, rows_per_chunk=r, prefetch=p, xcd_swizzle=s, fuse=f, wide=w, stagger=g,
-                              multistep=m)
-                         for r, p, s, f, w, g, m in itertools.product(args.ry, args.pf, args.swz, args.fuse,
-                                                                      args.wide, args.stagger, args.multistep)
-                         if not (w and (f < 3 or m == 0))]
+                cfgs += [dict(variant=v, rows_per_chunk=r, prefetch=p, xcd_swizzle=s, fuse=f)
+                         for r, p, s, f in itertools.product(args.ry, args.pf, args.swz, args.fuse)]
             elif v == 2:
                 cfgs += [dict(variant=2, rows_per_chunk=r, prefetch=0, xcd_swizzle=s, fuse=0)
                          for r, s in itertools.product(args.ry, args.swz)]
