@@ -13,11 +13,26 @@ scaling of the same global grid: one process per GPU, 2D block decomposition by 
 MPI_Dims_create rule, halos over RCCL send/recv on a second HIP stream.  torch.distributed
 (gloo) is only the control plane: unique-id broadcast, barrier, max-over-ranks.
 
-Rank 0 prints ONE JSON line.  Extra objects: `roofline` (dominant kernel = the fused sweep;
-algorithmic bytes = 16 B per cell update; duration from HIP events on the compute stream
-around every sweep launch of the timed region) and, at N = 1, `cpu_baseline` (the compiled
-reference objects, oracle/_ref/ref_run under mpirun, on a bounded sample — or the oracle port
-when that binary cannot run).
+Rank 0 prints ONE JSON line.  Extra objects:
+
+`roofline` (dominant kernel = the fused sweep, HBM side).  The sweep advances T time steps per HBM
+  pass (temporal blocking in registers), so three byte counts exist per launch and the line names
+  each one:
+    traffic                        what really moved: rocprofv3 PMC bytes of this kernel (FETCH_SIZE x 2 +
+                                   WRITE_SIZE, separate passes, profiles/pmc_traffic.json), looked up by the
+                                   kernel instantiation (T) and grid that were timed here
+    algorithmic_bytes_per_launch   what one launch must move at least: 16 B x cells (each cell read
+                                   once and written once per pass)
+    step_equivalent_bytes          16 B x cells x T: what a one-step-per-pass sweep would move for the
+                                   same T updates (the figure SURVEY §8d's 16 B per cell-UPDATE gives)
+  `achieved` = traffic / (HIP-event kernel time measured live in the timed region) and `frac` =
+  achieved / 8 TB/s are therefore a true bandwidth and a true fraction (<= 1); the step-equivalent
+  rate, which exceeds the HBM peak by construction, is reported beside them as
+  `step_equivalent_gbs` / `step_equivalent_x_peak` and never as `frac`.
+`roofline_valu`: the resource that actually binds the T >= 4 kernels — fp64 VALU issue (the
+  reference's own 15 non-FMA fp64 operations per cell update; FMA contraction would change bits).
+`cpu_baseline` (N = 1): the compiled reference objects (oracle/_ref/ref_run under mpirun) and the
+  oracle port (checked / unchecked accessor flavours) on bounded samples, host core counts stated.
 """
 from __future__ import annotations
 
@@ -31,8 +46,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_COPY_GBS = 6290.0       # same guide: float4 copy, what a streaming kernel can reach
 BYTES_PER_CELL = 16.0       # one 8-byte read of u + one 8-byte write of u'
+FP64_OPS_PER_UPDATE = 15    # non-FMA fp64 add/mul per cell update with dx = dy = 1 (csrc/kernels.hip cell<>)
+# vector fp64 peak: 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz = 39.3 T non-FMA op/s (78.6 TFLOP/s as FMA)
+FP64_VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 
 # BASELINE.json `metric`: 16384^2 fp64; physics of configs[2]/[3]
 NX = NY = 16384
@@ -40,33 +59,154 @@ PHYS = dict(D=0.05, vx=0.5, vy=0.25, dt=0.1)
 BC = "dddd"
 
 
-def cpu_baseline(cores: int):
-    """Reference CPU path on the host cores, bounded sample of the same workload."""
+# ---------------------------------------------------------------------------------------------
+# CPU baseline: a reported baseline, never the target
+# ---------------------------------------------------------------------------------------------
+def host_cpu_info():
+    """logical / physical core counts of the box and what this process may use of them"""
+    logical = os.cpu_count() or 1
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except Exception:
+        affinity = logical
+    cores, model = set(), ""
+    try:
+        phys = core = None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name") and not model:
+                model = ln.split(":", 1)[1].strip()
+            elif ln.startswith("physical id"):
+                phys = ln.split(":", 1)[1].strip()
+            elif ln.startswith("core id"):
+                core = ln.split(":", 1)[1].strip()
+            elif not ln.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except Exception:
+        pass
+    quota = None
+    for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(f).read().split()
+            if f.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except Exception:
+            continue
+    return dict(nproc_logical=logical, physical_cores=len(cores) or None, affinity=affinity,
+                cgroup_cpu_quota=quota, model=model)
+
+
+def cpu_baseline():
+    """Reference CPU path on the host cores, bounded samples of the same workload (about 20 s)."""
     from oracle import cpu_oracle as ora
-    nx = ny = int(os.environ.get("CSIM_BENCH_CPU_N", NX))
+    host = host_cpu_info()
+    usable = host["affinity"]
+    if host["cgroup_cpu_quota"]:
+        usable = max(1, min(usable, int(host["cgroup_cpu_quota"])))
+    # the GPU pool gives a one-GPU lease a 16-core share of the host (more threads would run on cores
+    # that belong to other leases): use every usable core up to that share unless told otherwise
+    share = int(os.environ.get("CSIM_BENCH_CPU_CORES", 16))
+    cores = max(1, min(usable, share))
+    host.update(usable=usable, used=cores,
+                cap="min(usable, 16): the pool's CPU share of a one-GPU lease (override: CSIM_BENCH_CPU_CORES)")
+    nx = int(os.environ.get("CSIM_BENCH_CPU_N", NX))
     steps = int(os.environ.get("CSIM_BENCH_CPU_STEPS", 4))
+    small_n, small_steps = int(os.environ.get("CSIM_BENCH_CPU_SMALL_N", 4096)), 40
+    variants = []
+
+    def rate(n, k, secs):
+        return n * n * k / secs / 1e6
+
+    def reference(n, k):
+        t0 = time.time()
+        out = ora.ref_run("run", np_ranks=cores, timeout=600, nx=n, ny=n, steps=k, bc=BC, ic="gaussian", **PHYS)
+        wall = time.time() - t0
+        loop_s = float(re.search(r"timing: total_max=([0-9.eE+-]+) s", out).group(1))
+        variants.append(dict(kind="reference", grid=f"{n}x{n}", steps=k, value=rate(n, k, loop_s), cores=cores,
+                             how=f"oracle/_ref/ref_run (the reference's own translation units, g++ -O2, "
+                                 f"bounds-checked Field::at) under mpirun -np {cores}; loop {loop_s:.2f} s, "
+                                 f"whole run {wall:.1f} s"))
+        return variants[-1]
+
+    def port(n, k, checked):
+        w = ora.World(cores, n, n, 1.0, 1.0)
+        w.gaussian()
+        secs = w.run(PHYS["D"], PHYS["vx"], PHYS["vy"], PHYS["dt"], ora.bc_codes(BC), k, threads=cores,
+                     checked=checked)
+        how = "Field::at-style double bounds check on every access" if checked else "row pointers, no bounds checks"
+        variants.append(dict(kind="port-checked" if checked else "port-unchecked", grid=f"{n}x{n}", steps=k,
+                             value=rate(n, k, secs), cores=cores,
+                             how=f"oracle/cpu_stepper.c, {cores} tiles on {cores} threads, {how}; loop {secs:.2f} s"))
+        return variants[-1]
+
+    head = None
     if ora.have_reference():
         try:
-            t0 = time.time()
-            out = ora.ref_run("run", np_ranks=cores, timeout=600, nx=nx, ny=ny, steps=steps,
-                              bc=BC, ic="gaussian", **PHYS)
-            wall = time.time() - t0
-            m = re.search(r"timing: total_max=([0-9.eE+-]+) s", out)
-            loop_s = float(m.group(1))
-            return dict(value=nx * ny * steps / loop_s / 1e6, unit="Mcell-updates/s", cores=cores,
-                        kind="reference",
-                        sample=f"{nx}x{ny} fp64, {steps} steps, oracle/_ref/ref_run (reference "
-                               f"objects, g++ -O2) under mpirun -np {cores}; loop {loop_s:.2f} s, "
-                               f"whole run {wall:.1f} s")
-        except Exception as e:  # mpirun unusable on this box: fall back to the port
+            head = reference(nx, steps)
+            reference(small_n, small_steps)
+        except Exception as e:  # mpirun unusable on this box: the port carries the baseline
             sys.stderr.write(f"[bench] reference baseline unavailable ({e}); using the port\n")
-    w = ora.World(cores, nx, ny, 1.0, 1.0)
-    w.gaussian()
-    secs = w.run(PHYS["D"], PHYS["vx"], PHYS["vy"], PHYS["dt"], ora.bc_codes(BC), steps,
-                 threads=cores)
-    return dict(value=nx * ny * steps / secs / 1e6, unit="Mcell-updates/s", cores=cores, kind="port",
-                sample=f"{nx}x{ny} fp64, {steps} steps, oracle/cpu_stepper.c with {cores} threads "
-                       f"(one tile per thread); loop {secs:.2f} s")
+    p_un = port(nx, steps, False)
+    port(nx, steps, True)
+    port(small_n, small_steps, False)
+    port(small_n, small_steps, True)
+    if head is None:
+        head = p_un
+    return dict(value=head["value"], unit="Mcell-updates/s", cores=cores,
+                kind="reference" if head["kind"] == "reference" else "port",
+                sample=f"{head['grid']} fp64, {head['steps']} steps of the bench workload; {head['how']}",
+                host=host, variants=variants)
+
+
+# ---------------------------------------------------------------------------------------------
+# profile look-ups (files written by tools/gpu_pmc.sh / tools/gpu_pmc_sq.sh on a GPU box)
+# ---------------------------------------------------------------------------------------------
+def kernel_label(T):
+    return "k_sweep_dpp" if T == 1 else f"k_sweepO_dpp<T={T}>"
+
+
+def lookup_traffic(nx, ny, T, bc):
+    """PMC HBM bytes per launch of the sweep instantiation that was timed: same T, same local grid.
+    Falls back to the per-cell figure of another grid of the same T (flagged) — the traffic per cell
+    of a streaming sweep does not depend on the grid once it is far beyond the 256 MiB Infinity Cache."""
+    f = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        entries = json.load(open(f)).get("entries", [])
+    except Exception:
+        return None, "profiles/pmc_traffic.json missing"
+    same_t = [e for e in entries if e.get("steps_per_launch") == T]
+    exact = [e for e in same_t if e.get("nx") == nx and e.get("ny") == ny]
+    pick = [e for e in exact if e.get("bc") == bc] or exact
+    if pick:
+        e = pick[0]
+        return e["hbm_bytes_per_launch"], (
+            f"profiles/pmc_traffic.json '{e['kernel']}' {e['nx']}x{e['ny']} bc={e.get('bc')}: rocprofv3 --pmc "
+            f"FETCH_SIZE / WRITE_SIZE in separate passes, (2 x FETCH_SIZE + WRITE_SIZE) KiB (gfx950 FETCH correction)")
+    big = [e for e in same_t if e.get("nx", 0) * e.get("ny", 0) * 8 >= (1 << 29)]
+    if big and nx * ny * 8 >= (1 << 29):
+        e = big[0]
+        per_cell = e["hbm_bytes_per_launch"] / (e["nx"] * e["ny"])
+        return per_cell * nx * ny, (f"SCALED per cell from profiles/pmc_traffic.json '{e['kernel']}' "
+                                    f"{e['nx']}x{e['ny']} ({per_cell:.2f} B per cell per launch)")
+    return None, f"no PMC entry for T={T} on {nx}x{ny}"
+
+
+def lookup_valu(T):
+    f = os.path.join(ROOT, "profiles", "sq_valu.json")
+    try:
+        for e in json.load(open(f)).get("entries", []):
+            if e.get("steps_per_launch") == T:
+                return e
+    except Exception:
+        pass
+    return None
 
 
 def main():
@@ -79,6 +219,10 @@ def main():
                          "clocks (a cold MI355X runs its first ~30 ms about 15 %% below the sustained rate)")
     ap.add_argument("--nx", type=int, default=NX)
     ap.add_argument("--ny", type=int, default=NY)
+    ap.add_argument("--bc", default=BC, help="boundary mix left/right/bottom/top, e.g. dddd (default), nnnn, dnpd")
+    ap.add_argument("--contract", type=int, default=0,
+                    help="0 (default): the reference's own operation order, bit-identical results; 1: opt-in "
+                         "contracted arithmetic (see csim.h option \"contract\"), within 1e-10 of the reference")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--rows-per-chunk", type=int, default=0)
@@ -90,6 +234,7 @@ def main():
     ap.add_argument("--fuse", type=int, default=-1,
                     help="time steps per HBM pass: -1 auto (deepest available), 0 off, 2..6")
     args = ap.parse_args()
+    assert len(args.bc) == 4 and set(args.bc) <= set("dnp"), "--bc takes four of d/n/p"
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -104,8 +249,7 @@ def main():
     # CPU baseline first: it forks mpirun, which must happen before this process touches the GPU
     cpu = None
     if world == 1 and not self_torus and not args.no_cpu_baseline:
-        cores = min(16, os.cpu_count() or 1)
-        cpu = cpu_baseline(cores)
+        cpu = cpu_baseline()
 
     import torch  # noqa: F401  (plumbing: torch.distributed control plane; also pins ONE HIP runtime)
     import torch.distributed as dist
@@ -126,7 +270,7 @@ def main():
     if self_torus:
         for k in range(4):
             dec.nbr[k] = 0
-    st = csim.Stepper(dec, 1.0, 1.0, csim.bc_codes(BC), 0.0)
+    st = csim.Stepper(dec, 1.0, 1.0, csim.bc_codes(args.bc), 0.0)
     halo = "rccl" if multi else "none"
     if multi:
         # RCCL communicator (unique id over the gloo control plane).  If it cannot be built on this
@@ -157,6 +301,8 @@ def main():
                      ("prefetch", args.prefetch), ("overlap", 0 if args.no_overlap else 1),
                      ("fuse", args.fuse)):
         st.set_option(key, val)
+    if args.contract:
+        st.set_option("contract", args.contract)
     if args.lds_bytes:
         st.set_option("lds_bytes", args.lds_bytes)
     st.init_gaussian(1.0, 0.05, 0.5, 0.5)
@@ -251,7 +397,7 @@ def main():
     advance(args.steps)
     st.sync()
     t1 = time.perf_counter()
-    elapsed = t1 - t0
+    elapsed_local = elapsed = t1 - t0
     if multi:
         dist.barrier()
         t = torch.tensor([elapsed], dtype=torch.float64)
@@ -261,14 +407,27 @@ def main():
     kinds = {t: st.kernel_time(t) for t in (1, 2, 3, 4, 5, 6)}
     steps_per_launch = max(kinds, key=lambda t: t * kinds[t][1])
     kern_ms, launches = kinds[steps_per_launch]
+    comm_ms, comm_n = st.comm_time()
     mn, mx = st.minmax()
     tuned_rows = st.get_option("tuned_rows") or (args.rows_per_chunk or "heuristic")
+    last_rows = st.get_option("last_rows")
+    overlap_now = st.get_option("overlap")
     mass1 = global_sum()
     mass_drift = abs(mass1 - mass0) / abs(mass0)
     if mass_drift > 1e-9 and rank == 0:
         sys.stderr.write(f"[bench] WARNING: total mass drifted by {mass_drift:.3e} (halo exchange broken?)\n")
     st.close()
+    kern_avg_local = kern_ms / max(launches, 1)
+    per_rank = None
     if multi:
+        # every rank's own figures, so that a slow or skewed rank is visible in the one line
+        mine = dict(rank=rank, coords=[dec.coords[0], dec.coords[1]], local=[dec.nx_local, dec.ny_local],
+                    neighbours=list(dec.nbr), wall_ms_per_step=elapsed_local / args.steps * 1e3,
+                    kernel=kernel_label(steps_per_launch), kernel_avg_ms=kern_avg_local, launches_timed=launches,
+                    exchange_chain_avg_ms=(comm_ms / comm_n) if comm_n else None, exchange_chains_timed=comm_n,
+                    rows_per_chunk=last_rows, overlap=overlap_now)
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
         km = torch.tensor([kern_ms], dtype=torch.float64)
         dist.all_reduce(km, op=dist.ReduceOp.MAX)
         kern_ms = float(km.item())
@@ -279,20 +438,74 @@ def main():
         cells = float(args.nx) * float(args.ny)
         value = cells * args.steps / elapsed / 1e6
         local_cells = float(dec.nx_local) * float(dec.ny_local)
-        # algorithmic bytes of ONE launch = 16 B x local cells x time steps that launch advances
-        ach = local_cells * BYTES_PER_CELL * steps_per_launch / (kern_avg_ms * 1e-3) / 1e9
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if world == 1 and os.path.exists(tfile):
-            try:
-                tj = json.load(open(tfile))
-                # PMC bytes were collected in separate rocprofv3 --pmc passes of this same command
-                # (tools/gpu_pmc.sh); only quoted when they belong to the kernel timed here
-                if (tj.get("nx") == args.nx and tj.get("ny") == args.ny
-                        and tj.get("steps_per_launch") == steps_per_launch):
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        T = steps_per_launch
+        secs = kern_avg_ms * 1e-3
+        alg_bytes = local_cells * BYTES_PER_CELL                 # one read + one write of the field per launch
+        step_eq_bytes = alg_bytes * T                            # what T one-step passes would move
+        if args.contract:
+            traffic, traffic_src = None, "contracted arithmetic: no PMC profile"
+        else:
+            traffic, traffic_src = lookup_traffic(dec.nx_local, dec.ny_local, T, args.bc)
+        if multi:
+            # the PMC profiles are of the whole-field launch; a multi-rank pass is frame + bulk launches
+            traffic_src += " (whole-field launch; this run splits a pass into frame + bulk launches)"
+        if traffic is not None:
+            ach_bytes, ach_src = traffic, "traffic (PMC)"
+        else:
+            ach_bytes, ach_src = alg_bytes, "algorithmic_bytes_per_launch (no PMC entry: a LOWER bound of the real traffic)"
+        ach = ach_bytes / secs / 1e9
+        roofline = {
+            "bound": "hbm",
+            "achieved": ach,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "achieved_from": ach_src,
+            "traffic_source": traffic_src,
+            "frac_of_measured_copy_peak": ach / HBM_COPY_GBS,
+            "kernel": kernel_label(T) + f" (fused copy+diffusion+advection, {T} time step(s) per HBM pass)",
+            "kernel_avg_ms": kern_avg_ms,
+            "launches_timed": launches,
+            "time_steps_per_launch": T,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "algorithmic_gbs": alg_bytes / secs / 1e9,
+            "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
+            "step_equivalent_bytes": step_eq_bytes,
+            "step_equivalent_gbs": step_eq_bytes / secs / 1e9,
+            "step_equivalent_x_peak": step_eq_bytes / secs / 1e9 / HBM_PEAK_GBS,
+            "note": "frac = PMC traffic / live kernel time / 8 TB/s.  step_equivalent_* counts 16 B per cell-UPDATE "
+                    "(SURVEY §8d) and exceeds the peak because T time levels stay in registers per pass; it is "
+                    "the figure to compare with a one-step-per-pass sweep, not a bandwidth",
+        }
+        ops_per_update = FP64_OPS_PER_UPDATE if not args.contract else 5
+        useful_tops = local_cells * T * ops_per_update / secs / 1e12
+        valu = lookup_valu(T) if not args.contract else None
+        roofline_valu = {
+            "bound": "fp64-valu",
+            "achieved": useful_tops,
+            "peak": FP64_VALU_PEAK_TOPS,
+            "unit": "T fp64 op/s (non-FMA add/mul)",
+            "frac": useful_tops / FP64_VALU_PEAK_TOPS,
+            "useful_ops_per_cell_update": ops_per_update,
+            "note": "useful = the reference's own operations per cell update x updates per launch / live kernel "
+                    "time; peak = 256 CUs x 4 SIMDs x 16 fp64 lanes/clk x 2.4 GHz (FMA would double the FLOP "
+                    "count but change the bits)",
+        }
+        if valu:
+            insts = valu["SQ_INSTS_VALU"]
+            fp64_share = valu.get("fp64_share", 180.0 / 204.0)
+            executed = insts * 64 * fp64_share / secs / 1e12
+            roofline_valu.update(
+                insts_per_launch=insts,
+                executed_fp64_tops=executed,
+                executed_frac=executed / FP64_VALU_PEAK_TOPS,
+                redundancy_executed_over_useful=executed / useful_tops,
+                sustained_clock_ghz_under_counters=valu.get("clock_ghz"),
+                source=f"profiles/sq_valu.json ({valu.get('kernel')}, {valu.get('nx')}x{valu.get('ny')}): SQ_INSTS_VALU "
+                       f"per launch, {fp64_share:.3f} of them fp64 add/mul (rest: DPP lane shifts), clock = "
+                       f"GRBM_GUI_ACTIVE / 8 / kernel time in that PMC run")
+        n_launch_total = args.steps / T
         line = {
             "metric": "Mcell-updates/sec (16384^2 fp64 advection-diffusion sweep)",
             "value": value,
@@ -308,37 +521,29 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{args.nx}x{args.ny} fp64 gaussian hotspot, D={PHYS['D']} "
-                            f"v=({PHYS['vx']},{PHYS['vy']}) dt={dt} dx=dy=1, all-Dirichlet(0), "
+                            f"v=({PHYS['vx']},{PHYS['vy']}) dt={dt} dx=dy=1, bc={args.bc} "
+                            f"(left/right/bottom/top: d=Dirichlet(0) n=Neumann p=Periodic), "
                             f"decomp {dec.dims[0]}x{dec.dims[1]} (local {dec.nx_local}x{dec.ny_local}), "
                             f"halo overlap {'off' if args.no_overlap else 'on'}"
+                            + (", contracted arithmetic (NOT bit-identical; opt-in)" if args.contract else "")
                             + (" — TEST MODE: one rank linked to itself in all 8 directions" if self_torus else ""),
                 "halo_transport": halo,
                 "exchange_schedules_ms_per_step": exchange_modes,
-                "hbm_gbs_whole_job": cells * args.steps * BYTES_PER_CELL / elapsed / 1e9,
+                "hbm_gbs_whole_job": (traffic * n_launch_total * world / elapsed / 1e9) if traffic else None,
+                "hbm_gbs_whole_job_is": "PMC bytes per launch x launches of the timed region (x ranks) / wall time: "
+                                        "real HBM traffic per second of the whole job",
+                "step_equivalent_gbs_whole_job": cells * args.steps * BYTES_PER_CELL / elapsed / 1e9,
                 "field_min_max_after_run": [mn, mx],
                 "relative_mass_drift": mass_drift,
                 "untimed_clock_ramp_steps": ramp_steps,
                 "rows_per_chunk": tuned_rows,
+                "rows_per_chunk_last_launch": last_rows,
+                "per_rank": per_rank,
+                "scaling_note": None if world == 1 else "N > 1 over real xGMI was never timed by the builder "
+                                                        "(one-GPU lease): this line is the first measurement",
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": ach,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS,
-                "traffic": traffic,
-                # what really moved through HBM per second (PMC bytes / live kernel time): the kernel
-                # advances 6 time steps per pass, so `achieved` (algorithmic) exceeds the peak while
-                # the real traffic stays below it
-                "traffic_gbs": (traffic / (kern_avg_ms * 1e-3) / 1e9) if traffic else None,
-                "traffic_frac_of_peak": (traffic / (kern_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                "kernel": ("k_sweep_dpp" if steps_per_launch == 1 else f"k_sweepO_dpp<T={steps_per_launch}>") +
-                          f" (fused copy+diffusion+advection, {steps_per_launch} time step(s) per HBM pass)",
-                "kernel_avg_ms": kern_avg_ms,
-                "launches_timed": launches,
-                "time_steps_per_launch": steps_per_launch,
-                "algorithmic_bytes_per_launch": local_cells * BYTES_PER_CELL * steps_per_launch,
-            },
+            "roofline": roofline,
+            "roofline_valu": roofline_valu,
         }
         if cpu is not None:
             line["cpu_baseline"] = cpu

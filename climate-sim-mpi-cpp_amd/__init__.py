@@ -137,6 +137,7 @@ def lib() -> C.CDLL:
         "csim_stepper_set_option": (i, [vp, C.c_char_p, C.c_long]),
         "csim_stepper_get_option": (i, [vp, C.c_char_p, C.POINTER(C.c_long)]),
         "csim_stepper_kernel_time": (i, [vp, i, dp, C.POINTER(C.c_long)]),
+        "csim_stepper_comm_time": (i, [vp, dp, C.POINTER(C.c_long)]),
         "csim_stepper_reset_timers": (i, [vp]),
     }
     for name, (res, args) in sig.items():
@@ -423,6 +424,12 @@ class Stepper:
             return one(steps_per_launch)
         parts = [(t,) + one(t) for t in (1, 2, 3, 4, 5, 6)]
         return (sum(p[1] for p in parts), sum(p[2] for p in parts), sum(p[0] * p[2] for p in parts))
+
+    def comm_time(self):
+        """(total ms, passes) of the sampled comm-stream chains (pack + RCCL exchange + unpack + ghost fill)"""
+        ms, n = C.c_double(), C.c_long()
+        _ck(lib().csim_stepper_comm_time(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def reset_timers(self):
         _ck(lib().csim_stepper_reset_timers(self._h))

@@ -143,6 +143,7 @@ struct csim_stepper {
     hipStream_t s_io = nullptr;
     hipEvent_t ev_snap_src = nullptr, ev_snap_copied = nullptr;
     bool snap_pending = false;
+    int last_rows = 0;    // chunk height the last fused whole-field / bulk launch used
     int fuse_cap = 1;     // deepest pass every rank of the decomposition can run (same on all ranks)
     int faces_depth = 0;  // recv2[] holds the neighbours' faces of `cur` of this depth (0 = none)
     SweepCfg cfg;
@@ -159,14 +160,16 @@ struct csim_stepper {
     int external = 0;  // halos are carried by the caller (csim_stepper_halo_pack/_unpack), not RCCL
     int profile = 0;        // 0 off, k >= 1: HIP events around every k-th pass
     bool prof_active = false;
+    long prof_slot = -1;
     unsigned long prof_counter = 0;
     int autotune = 1;     // pick rows_per_chunk (when 0 = auto) by timing trial launches on this GPU
     bool tuned = false;
     std::vector<hipEvent_t> ev_pool;  // start/stop pairs around sweep launches
     std::vector<int> ev_steps;        // time steps covered by each timed launch
     size_t ev_used = 0;
-    double prof_ms[MAX_FUSE + 1]{};     // indexed by time steps per launch (1..MAX_FUSE)
-    long prof_launches[MAX_FUSE + 1]{};
+    static constexpr int PROF_COMM = MAX_FUSE + 1;  // comm-stream chain of a pass: pack, RCCL group, unpack, ghost fill
+    double prof_ms[MAX_FUSE + 2]{};     // indexed by time steps per launch (1..MAX_FUSE), [PROF_COMM]
+    long prof_launches[MAX_FUSE + 2]{};
     size_t bytes() const { return sizeof(double) * static_cast<size_t>(ny + 2 + 2 * GHOST_EXTRA) * pitch; }
     // whole-allocation pointer of a view
     double* base(double* view) const { return view - static_cast<size_t>(GHOST_EXTRA) * pitch; }
@@ -805,6 +808,7 @@ int csim_stepper_exchange_halos(csim_stepper* s) {
 static int prof_fold(csim_stepper* s) {
     if (s->ev_used == 0) return CSIM_OK;
     CSIM_HIP(hipStreamSynchronize(s->s_comp));
+    CSIM_HIP(hipStreamSynchronize(s->s_comm));
     for (size_t k = 0; k + 1 < s->ev_used; k += 2) {
         float ms = 0.f;
         CSIM_HIP(hipEventElapsedTime(&ms, s->ev_pool[k], s->ev_pool[k + 1]));
@@ -816,33 +820,48 @@ static int prof_fold(csim_stepper* s) {
     return CSIM_OK;
 }
 
-static int prof_begin(csim_stepper* s, int steps) {
-    constexpr size_t POOL = 2048;
-    // profile = k > 1: only every k-th pass is bracketed (two event records cost a few microseconds
-    // of stream time each, which shows on the ~170 us passes of a small multi-rank tile)
-    s->prof_active = s->profile > 0 && (s->prof_counter++ % s->profile) == 0;
+// one start/stop event pair of the current (sampled) pass: start recorded now on `st`; kind = time
+// steps of the sweep launch (1..MAX_FUSE) or PROF_COMM for the comm-stream chain of a pass
+static int prof_start(csim_stepper* s, int kind, hipStream_t st, long* slot) {
+    *slot = -1;
     if (!s->prof_active) return CSIM_OK;
-    if (s->ev_used + 2 > POOL) {
-        int rc = prof_fold(s);
-        if (rc) return rc;
-    }
     while (s->ev_pool.size() < s->ev_used + 2) {
         hipEvent_t ev;
         CSIM_HIP(hipEventCreate(&ev));
         s->ev_pool.push_back(ev);
     }
     if (s->ev_steps.size() < s->ev_pool.size() / 2) s->ev_steps.resize(s->ev_pool.size() / 2);
-    s->ev_steps[s->ev_used / 2] = steps;
-    CSIM_HIP(hipEventRecord(s->ev_pool[s->ev_used], s->s_comp));
+    s->ev_steps[s->ev_used / 2] = kind;
+    CSIM_HIP(hipEventRecord(s->ev_pool[s->ev_used], st));
+    *slot = static_cast<long>(s->ev_used);
+    s->ev_used += 2;
     return CSIM_OK;
+}
+
+static int prof_stop(csim_stepper* s, long slot, hipStream_t st) {
+    if (slot < 0) return CSIM_OK;
+    CSIM_HIP(hipEventRecord(s->ev_pool[static_cast<size_t>(slot) + 1], st));
+    return CSIM_OK;
+}
+
+static int prof_begin(csim_stepper* s, int steps) {
+    constexpr size_t POOL = 2048;
+    // profile = k > 1: only every k-th pass is bracketed (two event records cost a few microseconds
+    // of stream time each, which shows on the ~170 us passes of a small multi-rank tile)
+    s->prof_active = s->profile > 0 && (s->prof_counter++ % s->profile) == 0;
+    if (!s->prof_active) return CSIM_OK;
+    if (s->ev_used + 4 > POOL) {
+        int rc = prof_fold(s);
+        if (rc) return rc;
+    }
+    return prof_start(s, steps, s->s_comp, &s->prof_slot);
 }
 
 static int prof_end(csim_stepper* s) {
     if (!s->prof_active) return CSIM_OK;
+    int rc = prof_stop(s, s->prof_slot, s->s_comp);
     s->prof_active = false;
-    CSIM_HIP(hipEventRecord(s->ev_pool[s->ev_used + 1], s->s_comp));
-    s->ev_used += 2;
-    return CSIM_OK;
+    return rc;
 }
 
 static int join_frame(csim_stepper* s);
@@ -898,6 +917,7 @@ static hipError_t launch_fused(csim_stepper* s, const Phys& p, const int kind[4]
                                hipStream_t st, bool final_pass = false, int lds_bytes = 0) {
     SweepCfg cfg = s->cfg;
     if (lds_bytes > 0) cfg.lds_bytes = lds_bytes;
+    cfg.rows_used = &s->last_rows;
     return launch_sweepO(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, cfg, kind, s->bc_value, T, part, st,
                          final_pass ? s->fin : nullptr);
 }
@@ -998,6 +1018,9 @@ static int pass_fused(csim_stepper* s, const Phys& p, int T, int next_T, bool fi
         CSIM_HIP(launch_fused(s, p, kind, T, 1, s->s_comp));
         CSIM_HIP(hipEventRecord(s->ev_edge2, s->s_comp));
         CSIM_HIP(hipStreamWaitEvent(s->s_comm, s->ev_edge2, 0));
+        long comm_slot = -1;
+        rc = prof_start(s, csim_stepper::PROF_COMM, s->s_comm, &comm_slot);
+        if (rc) return rc;
         CSIM_HIP(launch_halo2_pack(s->nxt, s->nx, s->ny, s->pitch, next_T, s->send2, s->s_comm));
         rc = post_exchange2(s, next_T, s->s_comm);
         if (rc) return rc;
@@ -1010,6 +1033,8 @@ static int pass_fused(csim_stepper* s, const Phys& p, int T, int next_T, bool fi
             CSIM_HIP(launch_ghost_fill(s->nxt, s->cur, s->nx, s->ny, s->pitch, g, s->s_comm, next_T));
             s->pre_unpacked = true;
         }
+        rc = prof_stop(s, comm_slot, s->s_comm);
+        if (rc) return rc;
         CSIM_HIP(hipEventRecord(s->ev_recv2, s->s_comm));
         CSIM_HIP(launch_fused(s, p, kind, T, 2, s->s_comp));
         s->faces_depth = next_T;
@@ -1216,8 +1241,8 @@ int csim_stepper_set_option(csim_stepper* s, const char* key, long value) {
         s->autotune = value != 0;
         s->tuned = false;
         s->cfg.tuned_rows = 0;
-    } else if (k == "tuned_rows") {  // read back through csim_stepper_get_option
-        return fail(CSIM_ERR_ARG, "tuned_rows is read-only");
+    } else if (k == "tuned_rows" || k == "last_rows") {  // read back through csim_stepper_get_option
+        return fail(CSIM_ERR_ARG, k + " is read-only");
     } else if (k == "profile") {
         CSIM_REQUIRE(value >= 0 && value <= 1024, "profile must be 0..1024");
         s->profile = static_cast<int>(value);
@@ -1234,6 +1259,7 @@ int csim_stepper_get_option(const csim_stepper* s, const char* key, long* value)
     if (k == "variant") *value = s->cfg.variant;
     else if (k == "rows_per_chunk") *value = s->cfg.rows_per_chunk;
     else if (k == "tuned_rows") *value = s->cfg.tuned_rows;
+    else if (k == "last_rows") *value = s->last_rows;
     else if (k == "prefetch") *value = s->cfg.prefetch;
     else if (k == "xcd_swizzle") *value = s->cfg.xcd_swizzle;
     else if (k == "overlap") *value = s->overlap;
@@ -1260,10 +1286,19 @@ int csim_stepper_reset_timers(csim_stepper* s) {
     CSIM_REQUIRE(s, "null stepper");
     int rc = prof_fold(s);
     if (rc) return rc;
-    for (int t = 0; t <= MAX_FUSE; ++t) {
+    for (int t = 0; t <= csim_stepper::PROF_COMM; ++t) {
         s->prof_ms[t] = 0.0;
         s->prof_launches[t] = 0;
     }
+    return CSIM_OK;
+}
+
+int csim_stepper_comm_time(csim_stepper* s, double* total_ms, long* passes) {
+    CSIM_REQUIRE(s && total_ms && passes, "null argument");
+    int rc = prof_fold(s);
+    if (rc) return rc;
+    *total_ms = s->prof_ms[csim_stepper::PROF_COMM];
+    *passes = s->prof_launches[csim_stepper::PROF_COMM];
     return CSIM_OK;
 }
 

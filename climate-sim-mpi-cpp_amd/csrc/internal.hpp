@@ -65,6 +65,7 @@ struct SweepCfg {
                              // (41 KB -> 3 workgroups per CU instead of 4), the kernel never touches it
     int prefetch = 0;        // 0 = auto (rows kept in flight per wavefront)
     int xcd_swizzle = 1;
+    int* rows_used = nullptr;  // out: chunk height of the last whole-field / bulk launch (option "last_rows")
 };
 
 // ---- kernel launchers (kernels.hip) --------------------------------------------------------

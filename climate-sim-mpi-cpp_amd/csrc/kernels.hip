@@ -977,6 +977,7 @@ static hipError_t sweepO_div(const double* in, double* out, int nx, int ny, int 
         ry += (6 - (ry + 2 * (T - 1)) % 6) % 6;
     }
     if (ry > ny) ry = ny;
+    if (cfg.rows_used && part != 1) *cfg.rows_used = ry;
     // part 0: the whole field.  part 1 / 2 (multi-rank pass): FRAME / BULK.  The frame is the
     // bottom and top bands (hf rows, all strips) plus the first strip and the last one or two
     // strips (>= MAX_FUSE columns) over the rows in between, in chunks of hf rows: thin tiles,

@@ -167,7 +167,8 @@ int csim_stepper_sum(csim_stepper* s, double* out);
  *                    (csim_stepper_kernel_time)
  *   "autotune"       0/1 (default 1) with rows_per_chunk = 0: the first long run times the candidate
  *                    chunk heights on this GPU (trial launches that do not advance the field) and keeps
- *                    the fastest; "tuned_rows" (read-only) reports it */
+ *                    the fastest; "tuned_rows" (read-only) reports it, "last_rows" (read-only) the chunk
+ *                    height the most recent fused launch actually used */
 int csim_stepper_set_option(csim_stepper* s, const char* key, long value);
 int csim_stepper_get_option(const csim_stepper* s, const char* key, long* value);
 /* with option "profile"=1: HIP-event time (on the compute stream) and count of the sweep
@@ -175,6 +176,11 @@ int csim_stepper_get_option(const csim_stepper* s, const char* key, long* value)
  * kernel, 2..6 the kernels that advance that many time steps per HBM pass */
 int csim_stepper_kernel_time(csim_stepper* s, int steps_per_launch, double* total_ms,
                              long* launches);
+/* same sampling, multi-rank runs over RCCL with "overlap" = 1: HIP-event time of the comm-stream chain
+ * of a pass — packing the next pass's faces, the grouped ncclSend/ncclRecv exchange, unpack and ghost
+ * fill — i.e. what the bulk sweep has to hide (replaces the blocking MPI_Waitall of reference
+ * src/halo.cpp:46) */
+int csim_stepper_comm_time(csim_stepper* s, double* total_ms, long* passes);
 int csim_stepper_reset_timers(csim_stepper* s);
 
 #ifdef __cplusplus

@@ -55,11 +55,14 @@ def lib() -> C.CDLL:
         L.ora_world_destroy.argtypes = [C.c_void_p]
         L.ora_world_scatter.argtypes = [C.c_void_p, dp]
         L.ora_world_gather.argtypes = [C.c_void_p, dp]
+        L.ora_world_gather_full.argtypes = [C.c_void_p, dp]
         L.ora_world_gaussian.argtypes = [C.c_void_p] + [C.c_double] * 4
         L.ora_world_tile_shape.argtypes = [C.c_void_p, C.c_int, ip]
         L.ora_world_tile_get.argtypes = [C.c_void_p, C.c_int, dp]
         L.ora_world_run.restype = C.c_double
         L.ora_world_run.argtypes = [C.c_void_p] + [C.c_double] * 4 + [ip, C.c_int, C.c_int]
+        L.ora_world_run_mode.restype = C.c_double
+        L.ora_world_run_mode.argtypes = [C.c_void_p] + [C.c_double] * 4 + [ip, C.c_int, C.c_int, C.c_int]
         L.ora_minmax.argtypes = [dp, C.c_size_t, dp]
         _lib = L
     return _lib
@@ -153,6 +156,13 @@ class World:
         lib().ora_world_gather(self._w, _dp(g))
         return g
 
+    def gather_full(self) -> np.ndarray:
+        """the world as one (nyg+2, nxg+2) array incl. the ghost ring of its physical sides: the full
+        local array of a 1-rank run (decomposition-invariant)."""
+        g = np.zeros((self.nyg + 2, self.nxg + 2))
+        lib().ora_world_gather_full(self._w, _dp(g))
+        return g
+
     def gaussian(self, A=1.0, sigma_frac=0.05, xc_frac=0.5, yc_frac=0.5):
         lib().ora_world_gaussian(self._w, A, sigma_frac, xc_frac, yc_frac)
 
@@ -163,8 +173,10 @@ class World:
         lib().ora_world_tile_get(self._w, r, _dp(a))
         return a
 
-    def run(self, D, vx, vy, dt, bc, steps, threads=1) -> float:
-        return lib().ora_world_run(self._w, D, vx, vy, dt, _i4(bc), steps, threads)
+    def run(self, D, vx, vy, dt, bc, steps, threads=1, checked=False) -> float:
+        """`steps` reference steps on every tile (threads > 1: tiles spread over threads); returns the
+        wall seconds.  checked=True: the bounds-checked accessor flavour (same results)."""
+        return lib().ora_world_run_mode(self._w, D, vx, vy, dt, _i4(bc), steps, threads, 1 if checked else 0)
 
 
 # ---- the real reference, when oracle/_ref/ref_run has been built ------------------------

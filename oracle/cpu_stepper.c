@@ -124,6 +124,59 @@ void ora_advection_step(const double* u, double* out, int nx, int ny, double dx,
     }
 }
 
+/* ---- bounds-checked accessor flavour (CPU-baseline variant only) ------------------------
+ * The reference reaches every element through Field::at = check_bounds (i, j against the local
+ * extents, src/field.cpp:14-18) + std::vector::at (index against size, :27-29).  These two
+ * functions restate diffusion_step / advection_step with that double check on all 5 + 1 and 3 + 2
+ * accesses per cell, so that bench.py can report the port both ways ("checked" is how the reference
+ * objects behave, "unchecked" what the same loops cost without the accessor). Same arithmetic. */
+static inline size_t idx_checked(int i, int j, int nxt, int nyt) {
+    if (i < 0 || i >= nxt || j < 0 || j >= nyt) abort();       /* check_bounds */
+    const size_t k = (size_t)j * (size_t)nxt + (size_t)i;
+    if (k >= (size_t)nxt * (size_t)nyt) abort();                /* vector::at */
+    return k;
+}
+#define ATC(f, i, j) ((f)[idx_checked((i), (j), nxt, nyt)])
+
+void ora_diffusion_step_checked(const double* u, double* out, int nx, int ny, double dx, double dy,
+                                double D, double dt) {
+    const int nxt = nx + 2, nyt = ny + 2;
+    for (int j = 1; j <= ny; ++j)
+        for (int i = 1; i <= nx; ++i) {
+            const double uij = ATC(u, i, j);
+            const double lap = (ATC(u, i + 1, j) - 2.0 * uij + ATC(u, i - 1, j)) / (dx * dx) +
+                               (ATC(u, i, j + 1) - 2.0 * uij + ATC(u, i, j - 1)) / (dy * dy);
+            ATC(out, i, j) = uij + dt * D * lap;
+        }
+    for (int i = 0; i < nxt; ++i) {
+        ATC(out, i, 0) = ATC(u, i, 0);
+        ATC(out, i, nyt - 1) = ATC(u, i, nyt - 1);
+    }
+    for (int j = 0; j < nyt; ++j) {
+        ATC(out, 0, j) = ATC(u, 0, j);
+        ATC(out, nxt - 1, j) = ATC(u, nxt - 1, j);
+    }
+}
+
+void ora_advection_step_checked(const double* u, double* out, int nx, int ny, double dx, double dy,
+                                double vx, double vy, double dt) {
+    const int nxt = nx + 2, nyt = ny + 2;
+    for (int j = 1; j <= ny; ++j)
+        for (int i = 1; i <= nx; ++i) {
+            double dudx, dudy;
+            if (vx >= 0.0)
+                dudx = (ATC(u, i, j) - ATC(u, i - 1, j)) / dx;
+            else
+                dudx = (ATC(u, i + 1, j) - ATC(u, i, j)) / dx;
+            if (vy >= 0.0)
+                dudy = (ATC(u, i, j) - ATC(u, i, j - 1)) / dy;
+            else
+                dudy = (ATC(u, i, j + 1) - ATC(u, i, j)) / dy;
+            const double adv = vx * dudx + vy * dudy;
+            ATC(out, i, j) += (-dt) * adv;
+        }
+}
+
 /* One reference time step on ONE tile whose ghosts already hold neighbour data on the
  * non-physical sides: boundary -> copy -> diffusion -> advection (src/main.cpp:102-107).
  * The caller swaps u and tmp afterwards (src/main.cpp:109). */
@@ -277,6 +330,29 @@ void ora_world_gather(const ora_world* w, double* g) {
     }
 }
 
+/* the world as ONE array with ghost ring, (nyg+2) x (nxg+2): interiors of all tiles plus the ghost
+ * lines of their PHYSICAL sides (span 1..n of the tile; the four global corners come from the
+ * corner tiles) — i.e. the full local array a 1-rank run of the reference would hold, which is
+ * decomposition-invariant (each ghost cell depends only on the boundary rule and its adjacent
+ * interior cell; the reference's side order L,R,B,T only matters at the global corners). */
+void ora_world_gather_full(const ora_world* w, double* g) {
+    const int gx = w->nxg + 2;
+    for (int r = 0; r < w->size; ++r) {
+        const ora_tile* t = &w->t[r];
+        const int nxt = t->nx + 2;
+        const int pl = t->nbr[ORA_LEFT] < 0, pr = t->nbr[ORA_RIGHT] < 0;
+        const int pb = t->nbr[ORA_BOTTOM] < 0, pt = t->nbr[ORA_TOP] < 0;
+        for (int j = 0; j <= t->ny + 1; ++j) {
+            const int row_ok = (j >= 1 && j <= t->ny) || (j == 0 && pb) || (j == t->ny + 1 && pt);
+            if (!row_ok) continue;
+            for (int i = 0; i <= t->nx + 1; ++i) {
+                const int col_ok = (i >= 1 && i <= t->nx) || (i == 0 && pl) || (i == t->nx + 1 && pr);
+                if (col_ok) AT(g, t->xo + i, t->yo + j, gx) = AT(t->u, i, j, nxt);
+            }
+        }
+    }
+}
+
 void ora_world_gaussian(ora_world* w, double A, double sigma_frac, double xc_frac,
                         double yc_frac) {
     for (int r = 0; r < w->size; ++r) {
@@ -326,6 +402,7 @@ typedef struct {
     double D, vx, vy, dt;
     int bc[4];
     pthread_barrier_t* bar;
+    int checked; /* 1: the bounds-checked accessor flavour of diffusion / advection */
 } ora_job;
 
 static void* world_worker(void* arg) {
@@ -338,8 +415,15 @@ static void* world_worker(void* arg) {
             ora_tile* t = &w->t[r];
             int phys[4];
             for (int k = 0; k < 4; ++k) phys[k] = t->nbr[k] < 0;
-            ora_step_tile(t->u, t->tmp, t->nx, t->ny, w->dx, w->dy, jb->D, jb->vx, jb->vy, jb->dt,
-                          jb->bc, phys);
+            if (jb->checked) {
+                ora_apply_boundary(t->u, t->nx, t->ny, jb->bc, phys, 0.0);
+                memcpy(t->tmp, t->u, sizeof(double) * (size_t)(t->nx + 2) * (size_t)(t->ny + 2));
+                ora_diffusion_step_checked(t->u, t->tmp, t->nx, t->ny, w->dx, w->dy, jb->D, jb->dt);
+                ora_advection_step_checked(t->u, t->tmp, t->nx, t->ny, w->dx, w->dy, jb->vx, jb->vy, jb->dt);
+            } else {
+                ora_step_tile(t->u, t->tmp, t->nx, t->ny, w->dx, w->dy, jb->D, jb->vx, jb->vy, jb->dt,
+                              jb->bc, phys);
+            }
             double* x = t->u;
             t->u = t->tmp;
             t->tmp = x;
@@ -349,15 +433,15 @@ static void* world_worker(void* arg) {
     return NULL;
 }
 
-/* returns wall seconds */
-double ora_world_run(ora_world* w, double D, double vx, double vy, double dt, const int bc[4],
-                     int steps, int threads) {
+/* returns wall seconds; checked = 1 selects the bounds-checked accessor flavour */
+double ora_world_run_mode(ora_world* w, double D, double vx, double vy, double dt, const int bc[4],
+                          int steps, int threads, int checked) {
     if (threads < 1) threads = 1;
     if (threads > w->size) threads = w->size;
     struct timespec a, b;
     clock_gettime(CLOCK_MONOTONIC, &a);
     if (threads == 1) {
-        ora_job jb = {w, 0, w->size, steps, D, vx, vy, dt, {bc[0], bc[1], bc[2], bc[3]}, NULL};
+        ora_job jb = {w, 0, w->size, steps, D, vx, vy, dt, {bc[0], bc[1], bc[2], bc[3]}, NULL, checked};
         world_worker(&jb);
     } else {
         pthread_barrier_t bar;
@@ -366,7 +450,7 @@ double ora_world_run(ora_world* w, double D, double vx, double vy, double dt, co
         ora_job* jobs = (ora_job*)calloc((size_t)threads, sizeof(ora_job));
         for (int k = 0; k < threads; ++k) {
             ora_job jb = {w,  (int)((long)w->size * k / threads), (int)((long)w->size * (k + 1) / threads),
-                          steps, D, vx, vy, dt, {bc[0], bc[1], bc[2], bc[3]}, &bar};
+                          steps, D, vx, vy, dt, {bc[0], bc[1], bc[2], bc[3]}, &bar, checked};
             jobs[k] = jb;
             pthread_create(&th[k], NULL, world_worker, &jobs[k]);
         }
@@ -377,6 +461,11 @@ double ora_world_run(ora_world* w, double D, double vx, double vy, double dt, co
     }
     clock_gettime(CLOCK_MONOTONIC, &b);
     return (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
+}
+
+double ora_world_run(ora_world* w, double D, double vx, double vy, double dt, const int bc[4],
+                     int steps, int threads) {
+    return ora_world_run_mode(w, D, vx, vy, dt, bc, steps, threads, 0);
 }
 
 /* reductions used around the loop (reference src/main.cpp:73-77 takes min/max over the whole

@@ -85,30 +85,59 @@ def test_self_exchange_torus(csim, sides, bc, overlap, shape):
     assert np.array_equal(got[mask], want[mask]), float(np.abs(got - want)[mask].max())
 
 
-def test_torus_at_tile_scale_overlap_equals_serial_single_steps(csim):
-    """a per-GPU-tile-sized torus (many strips x many chunks, so the frame / non-frame split and the
-    8-direction deep faces are all in play): the overlapped 6-step schedule must reproduce the
-    serial single-step schedule bit for bit."""
+def test_torus_at_tile_scale_every_schedule_equals_the_oracle(csim):
+    """a per-GPU-tile-sized torus (many strips x many chunks, so the frame / bulk split and the
+    8-direction deep faces are all in play): every exchange schedule — serial single steps, the
+    overlapped 6-step passes, the three-stream mode — must reproduce the ORACLE's torus bit for bit."""
     nx, ny, steps = 2048, 4096, 44
+    D, vx, vy, dt = 0.1, -0.5, 0.25, 0.1
     d = self_neighbor_decomp(csim, nx, ny, (1, 1, 1, 1))
-    ref = None
+    # hotspot sitting on a torus corner: all 8 faces carry data
+    u0 = ora.gaussian_global(nx, ny, sigma_frac=0.02, xc_frac=0.03, yc_frac=0.97)
+    want = torus_oracle(u0, 1.0, 1.0, D, vx, vy, dt, steps)[1:-1, 1:-1]
+    assert want[0, 0] > 0 and want[-1, -1] > 0 and want[0, -1] > 0 and want[-1, 0] > 0
     for opts in [dict(overlap=0, fuse=0), dict(overlap=1, fuse=-1), dict(overlap=0, fuse=-1),
-                 dict(overlap=1, fuse=4, rows_per_chunk=64), dict(overlap=1, fuse=3),
+                 dict(overlap=1, fuse=4, rows_per_chunk=64), dict(overlap=1, fuse=3), dict(overlap=1, fuse=5),
                  dict(overlap=2, fuse=-1), dict(overlap=2, fuse=4, rows_per_chunk=64),
                  dict(overlap=2, fuse=5, bulk_lds=0)]:
         st = csim.Stepper(d, 1.0, 1.0, csim.bc_codes("dddd"))
         st.comm_init(csim.comm_unique_id())
         for k, v in opts.items():
             st.set_option(k, v)
-        st.init_gaussian(1.0, 0.02, 0.03, 0.97)   # hotspot sitting on a torus corner: all 8 faces carry data
-        st.run(0.1, 0.1, -0.5, 0.25, steps)
+        st.upload(u0)
+        st.run(D, dt, vx, vy, steps)
         out = st.download_interior()
         st.close()
-        if ref is None:
-            ref = out
-            assert ref[0, 0] > 0 and ref[-1, -1] > 0 and ref[0, -1] > 0 and ref[-1, 0] > 0
-        else:
-            assert np.array_equal(out, ref), opts
+        assert np.array_equal(out, want), opts
+
+
+@pytest.mark.parametrize("sides,bc", [((1, 1, 0, 0), "ddnp"), ((0, 0, 1, 1), "pndd"), ((1, 1, 0, 0), "ddnn")])
+@pytest.mark.parametrize("overlap", [1, 2, 0])
+def test_torus_mixed_physical_and_linked_sides_depth6(csim, sides, bc, overlap):
+    """linked sides next to physical Neumann / Periodic sides on a tile tall and wide enough for the
+    frame / bulk split, three 6-step passes (overlapped exchange, comm-stream pre-unpack + ghost fill
+    with its halo extension, closing FinLines ghost fill): the FULL array incl. the ghost ring must be
+    the oracle's."""
+    nx, ny, steps = 1160, 300, 18
+    D, vx, vy, dt = 0.05, 0.5, -0.25, 0.1
+    rng = np.random.default_rng(23)
+    u0 = np.zeros((ny + 2, nx + 2))
+    u0[1:-1, 1:-1] = rng.standard_normal((ny, nx))
+    u0[0, :], u0[-1, :], u0[:, 0], u0[:, -1] = 0.5, -0.25, 0.125, -1.5   # Periodic ghosts must survive
+    codes = csim.bc_codes(bc)
+    want = torus_oracle(u0, 1.0, 1.0, D, vx, vy, dt, steps, sides, codes)
+    st = csim.Stepper(self_neighbor_decomp(csim, nx, ny, sides), 1.0, 1.0, codes)
+    st.comm_init(csim.comm_unique_id())
+    st.set_option("overlap", overlap)
+    st.set_option("profile", 1)
+    st.upload(u0)
+    st.run(D, dt, vx, vy, steps)
+    got = st.download()
+    assert st.kernel_time(6)[1] == 3
+    st.close()
+    mask = np.ones(got.shape, bool)
+    mask[[0, 0, -1, -1], [0, -1, 0, -1]] = False   # corners are never exchanged (SURVEY Q7)
+    assert np.array_equal(got[mask], want[mask]), float(np.abs(got - want)[mask].max())
 
 
 def test_exchange_halos_alone(csim):

@@ -18,7 +18,7 @@ def test_hip_stepper_multirank_one_gpu(world):
         assert rc == 0 and "ok=True" in out, (os.path.basename(case), out[-3000:])
 
 
-@pytest.mark.parametrize("depth", [2, 3, 4, 6])
+@pytest.mark.parametrize("depth", [2, 3, 4, 5, 6])
 @pytest.mark.parametrize("world", [2, 3, 4])
 def test_hip_stepper_fused_passes_multirank_one_gpu(world, depth):
     """2..6 steps per pass across ranks: deep faces incl. the diagonal corner blocks"""

@@ -342,18 +342,29 @@ def _window_check(csim, nx, ny, D, vx, vy, dt, bc, steps, opts, nwin, seed):
     u0 = np.zeros((ny + 2, nx + 2))
     u0[1:-1, 1:-1] = rng.random((ny, nx))
     st.upload(u0)
+    st.set_option("profile", 1)
     st.run(D, dt, vx, vy, steps)
     got = st.download()
+    # which kernel advanced the field, and with which chunk height
+    depth_used = max((1, 2, 3, 4, 5, 6), key=lambda t: t * st.kernel_time(t)[1])
+    rows_used = st.get_option("last_rows") if depth_used >= 2 else (opts or {}).get("rows_per_chunk", 64)
     st.close()
     W = 96
     anchors = [(1, 1), (nx - W + 1, 1), (1, ny - W + 1), (nx - W + 1, ny - W + 1)]
-    seams = [128, 512, 1024, nx // 2]
+    # strip seams of the overlapped-strip kernel lie at multiples of OverlapGeom<T>::STRIDE =
+    # 128 - 4 * ceil(T / 2) output columns (116 at T = 5, 6; 120 at T = 3, 4; 124 at T = 2), chunk
+    # seams at 1 + k * (rows the launch used): centre windows on both
+    stride = {2: 124, 3: 120, 4: 120, 5: 116, 6: 116}.get(depth_used, 128)
+    nstrips = (nx + stride - 1) // stride
+    nchunks = max(1, (ny + rows_used - 1) // rows_used) if rows_used > 0 else 1
     for k in range(nwin):
         if k < len(anchors):
             i0, j0 = anchors[k]
         else:
-            i0 = int(rng.choice(seams)) - W // 2 + int(rng.integers(-3, 4)) if k % 2 else int(rng.integers(1, nx - W))
-            j0 = int(rng.choice([64, 128, 256])) * int(rng.integers(1, max(2, ny // 256))) - W // 2 if k % 3 == 0 else int(rng.integers(1, ny - W))
+            i0 = (1 + stride * int(rng.integers(1, max(2, nstrips))) - W // 2 + int(rng.integers(-3, 4))) if k % 2 \
+                else int(rng.integers(1, nx - W))
+            j0 = (1 + rows_used * int(rng.integers(1, max(2, nchunks))) - W // 2 + int(rng.integers(-2, 3))) \
+                if (k % 3 == 0 and rows_used > 0) else int(rng.integers(1, ny - W))
             i0, j0 = max(1, min(i0, nx - W + 1)), max(1, min(j0, ny - W + 1))
         # expanded window, clipped at the physical edges (where the real BC applies)
         a0, a1 = max(1, i0 - steps), min(nx, i0 + W - 1 + steps)
@@ -384,6 +395,48 @@ def test_full_size_config3_8192_dirichlet(csim):
 
 def test_full_size_16384_windows(csim):
     _window_check(csim, 16384, 16384, 0.05, 0.5, 0.25, 0.1, "dnnd", 8, None, 10, 44)
+
+
+@pytest.mark.parametrize("bc", ["dddd", "dnnd"])
+@pytest.mark.parametrize("ic", ["gaussian", "random"])
+def test_full_field_16384_exactly_what_bench_times(csim, bc, ic):
+    """The WHOLE 16384 x 16384 field (ghost ring included) against the oracle, bit for bit, through the
+    very launches bench.py times: a 36-step run (>= 4 x depth, so the on-device chunk-height trial fires
+    and the six passes are k_sweepO_dpp<T=6> with the tuned rows), then 20 more steps on the same
+    stepper (4 passes of k_sweepO_dpp<T=5> with the tuned rows re-snapped — the schedule of the
+    driver's `bench.py --steps 20`).  Oracle: 16 tiles / 16 threads of oracle/cpu_stepper.c
+    (= the reference under mpirun -np 16), reassembled with its physical ghost lines."""
+    n = 16384
+    D, vx, vy, dt = 0.05, 0.5, 0.25, 0.1      # bench.py PHYS
+    if ic == "gaussian":
+        u0 = ora.gaussian_global(n, n)
+    else:
+        u0 = np.zeros((n + 2, n + 2))
+        u0[1:-1, 1:-1] = np.random.default_rng(160).random((n, n))
+    w = ora.World(16, n, n)
+    w.scatter(np.ascontiguousarray(u0[1:-1, 1:-1]))
+    st = csim.Stepper.single(n, n, 1.0, 1.0, csim.bc_codes(bc))
+    st.upload(u0)
+    del u0
+    st.set_option("profile", 1)
+    done = 0
+    for steps, depth, launches in [(36, 6, 6), (20, 5, 4)]:
+        st.reset_timers()
+        st.run(D, dt, vx, vy, steps)
+        got = st.download()
+        assert st.kernel_time(depth)[1] == launches, [st.kernel_time(t) for t in range(1, 7)]
+        assert sum(st.kernel_time(t)[1] for t in range(1, 7)) == launches
+        tuned = st.get_option("tuned_rows")
+        assert tuned > 0, "the chunk-height trial did not run"
+        last = st.get_option("last_rows")
+        assert tuned <= last < tuned + 6 and (last + 2 * (depth - 1)) % 6 == 0, (tuned, last)
+        w.run(D, vx, vy, dt, ora.bc_codes(bc), steps, threads=16)
+        want = w.gather_full()
+        done += steps
+        same = np.array_equal(got, want)
+        assert same, (bc, ic, done, float(np.abs(got - want).max()), int((got != want).sum()))
+        del got, want
+    st.close()
 
 
 def test_full_size_config5_32768_neumann(csim):

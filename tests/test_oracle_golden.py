@@ -49,6 +49,14 @@ def test_run_multi_tile_bit_exact(path):
         w.run(m["D"], m["vx"], m["vy"], dt, ora.bc_codes(m["bc"]), m["steps"],
               threads=min(p, 4))
         assert np.array_equal(w.gather(), z["u_final"]), p
+        # the tiles reassembled with the ghost lines of their physical sides == the full local array
+        # of the reference's own 1-rank run (what the full-size GPU parity tests compare against)
+        assert np.array_equal(w.gather_full(), z["local_np1_rank0"]), p
+        if p == m["ranks"][-1]:  # the bounds-checked accessor flavour (CPU-baseline variant): same bits
+            wc = ora.World(p, m["nx"], m["ny"], m["dx"], m["dy"])
+            wc.scatter(z["u0"])
+            wc.run(m["D"], m["vx"], m["vy"], dt, ora.bc_codes(m["bc"]), m["steps"], threads=2, checked=True)
+            assert np.array_equal(wc.gather_full(), z["local_np1_rank0"]), p
         for r in range(p):
             got, want = w.tile(r), z[f"local_np{p}_rank{r}"]
             assert got.shape == want.shape
