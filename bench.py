@@ -172,7 +172,7 @@ def kernel_label(T):
     return "k_sweep_dpp" if T == 1 else f"k_sweepO_dpp<T={T}>"
 
 
-def lookup_traffic(nx, ny, T, bc):
+def lookup_traffic(nx, ny, T, bc, rows=0):
     """PMC HBM bytes per launch of the sweep instantiation that was timed: same T, same local grid.
     Falls back to the per-cell figure of another grid of the same T (flagged) — the traffic per cell
     of a streaming sweep does not depend on the grid once it is far beyond the 256 MiB Infinity Cache."""
@@ -185,13 +185,15 @@ def lookup_traffic(nx, ny, T, bc):
     exact = [e for e in same_t if e.get("nx") == nx and e.get("ny") == ny]
     pick = [e for e in exact if e.get("bc") == bc] or exact
     if pick:
-        e = pick[0]
+        # several chunk heights were profiled (more rows per chunk = fewer overhead rows re-read): nearest one
+        e = min(pick, key=lambda e: abs(e.get("rows_per_chunk", 0) - rows))
         return e["hbm_bytes_per_launch"], (
-            f"profiles/pmc_traffic.json '{e['kernel']}' {e['nx']}x{e['ny']} bc={e.get('bc')}: rocprofv3 --pmc "
+            f"profiles/pmc_traffic.json '{e['kernel']}' {e['nx']}x{e['ny']} bc={e.get('bc')} rows_per_chunk="
+            f"{e.get('rows_per_chunk')}: rocprofv3 --pmc "
             f"FETCH_SIZE / WRITE_SIZE in separate passes, (2 x FETCH_SIZE + WRITE_SIZE) KiB (gfx950 FETCH correction)")
     big = [e for e in same_t if e.get("nx", 0) * e.get("ny", 0) * 8 >= (1 << 29)]
     if big and nx * ny * 8 >= (1 << 29):
-        e = big[0]
+        e = min(big, key=lambda e: (e.get("bc") != bc, abs(e.get("rows_per_chunk", 0) - rows)))
         per_cell = e["hbm_bytes_per_launch"] / (e["nx"] * e["ny"])
         return per_cell * nx * ny, (f"SCALED per cell from profiles/pmc_traffic.json '{e['kernel']}' "
                                     f"{e['nx']}x{e['ny']} ({per_cell:.2f} B per cell per launch)")
@@ -445,7 +447,7 @@ def main():
         if args.contract:
             traffic, traffic_src = None, "contracted arithmetic: no PMC profile"
         else:
-            traffic, traffic_src = lookup_traffic(dec.nx_local, dec.ny_local, T, args.bc)
+            traffic, traffic_src = lookup_traffic(dec.nx_local, dec.ny_local, T, args.bc, last_rows)
         if multi:
             # the PMC profiles are of the whole-field launch; a multi-rank pass is frame + bulk launches
             traffic_src += " (whole-field launch; this run splits a pass into frame + bulk launches)"

@@ -37,7 +37,7 @@ static bool pow2(double x) {
     return std::frexp(x, &e) == 0.5 && std::isnormal(1.0 / x);
 }
 
-Phys make_phys(double dx, double dy, double D, double dt, double vx, double vy) {
+Phys make_phys(double dx, double dy, double D, double dt, double vx, double vy, bool contract) {
     Phys p;
     p.kdiff = dt * D;
     p.mdt = -dt;
@@ -57,6 +57,21 @@ Phys make_phys(double dx, double dy, double D, double dt, double vx, double vy) 
         p.div_mode = 1;
     else
         p.div_mode = 2;
+    // coefficient form of the same update (option "contract"): collect what multiplies each of the five
+    // points in  c + dt D ((E - 2c + W)/dx^2 + (N - 2c + S)/dy^2) - dt (vx dudx + vy dudy)  with the
+    // upwind differences dudx = (c - W)/dx for vx >= 0, (E - c)/dx otherwise (dudy likewise)
+    {
+        const long double kx = static_cast<long double>(dt) * D / (static_cast<long double>(dx) * dx);
+        const long double ky = static_cast<long double>(dt) * D / (static_cast<long double>(dy) * dy);
+        const long double cx = static_cast<long double>(dt) * vx / dx, cy = static_cast<long double>(dt) * vy / dy;
+        const long double acx = cx < 0 ? -cx : cx, acy = cy < 0 ? -cy : cy;
+        p.a0 = static_cast<double>(1.0L - 2.0L * kx - 2.0L * ky - acx - acy);
+        p.aW = static_cast<double>(kx + (vx >= 0.0 ? acx : 0.0L));
+        p.aE = static_cast<double>(kx + (vx >= 0.0 ? 0.0L : acx));
+        p.aS = static_cast<double>(ky + (vy >= 0.0 ? acy : 0.0L));
+        p.aN = static_cast<double>(ky + (vy >= 0.0 ? 0.0L : acy));
+    }
+    if (contract) p.div_mode = 3;
     return p;
 }
 
@@ -157,6 +172,7 @@ struct csim_stepper {
     int bulk_lds = 41984;      // mode 2: dynamic LDS per bulk workgroup = 3 instead of 4 workgroups per CU, so
                                // that frame and RCCL workgroups always find a free slot
     int fuse = -1;  // time steps per HBM pass: -1 auto (deepest available), 0/1 off, 2..6 depth
+    int contract = 0;  // 1: opt-in contracted arithmetic (5-point FMA stencil), NOT bit-identical to the reference
     int external = 0;  // halos are carried by the caller (csim_stepper_halo_pack/_unpack), not RCCL
     int profile = 0;        // 0 off, k >= 1: HIP events around every k-th pass
     bool prof_active = false;
@@ -1131,7 +1147,7 @@ int csim_stepper_tune(csim_stepper* s, double D, double dt, double vx, double vy
     CSIM_REQUIRE(s, "null stepper");
     const int depth = fused_depth(s);
     if (depth < 2 || s->tuned || s->cfg.rows_per_chunk != 0) return CSIM_OK;
-    return tune_rows(s, make_phys(s->dx, s->dy, D, dt, vx, vy), depth);
+    return tune_rows(s, make_phys(s->dx, s->dy, D, dt, vx, vy, s->contract != 0), depth);
 }
 
 int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy, int nsteps) {
@@ -1150,7 +1166,7 @@ int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy,
     } else if (s->multi && !s->comm) {
         return fail(CSIM_ERR_STATE, "multi-rank stepper needs csim_stepper_comm_init before run");
     }
-    const Phys p = make_phys(s->dx, s->dy, D, dt, vx, vy);
+    const Phys p = make_phys(s->dx, s->dy, D, dt, vx, vy, s->contract != 0);
     const GhostArgs g = ghost_args(s);
     if (s->multi && s->external && nsteps >= 2) return pass_fused(s, p, nsteps, 0);
     // The ghost ring left in the field must be exactly the reference's: the halos / boundary values
@@ -1231,6 +1247,13 @@ int csim_stepper_set_option(csim_stepper* s, const char* key, long value) {
     } else if (k == "external_halo") {
         s->external = value != 0;
         s->halo_fresh = false;
+    } else if (k == "contract") {
+        CSIM_REQUIRE(value == 0 || value == 1, "contract must be 0 (reference operation order, default) or 1");
+        if (s->contract != static_cast<int>(value)) {  // another kernel: its best chunk height is found anew
+            s->tuned = false;
+            s->cfg.tuned_rows = 0;
+        }
+        s->contract = static_cast<int>(value);
     } else if (k == "fuse") {
         CSIM_REQUIRE(value >= -1 && value <= MAX_FUSE, "fuse must be -1 (auto) or 0..6");
         s->fuse = static_cast<int>(value);
@@ -1265,6 +1288,7 @@ int csim_stepper_get_option(const csim_stepper* s, const char* key, long* value)
     else if (k == "overlap") *value = s->overlap;
     else if (k == "external_halo") *value = s->external;
     else if (k == "fuse") *value = s->fuse;
+    else if (k == "contract") *value = s->contract;
     else if (k == "autotune") *value = s->autotune;
     else if (k == "profile") *value = s->profile;
     else return fail(CSIM_ERR_ARG, "unknown option: " + k);

@@ -51,8 +51,10 @@ struct Phys {
     double dx2, dy2;    // dx*dx, dy*dy: divisors of the second differences
     double rdx, rdy, rdx2, rdy2;  // exact reciprocals (only used when all four are powers of two)
     int div_mode;       // 0: dx == dy == 1 (x/1 is x)   1: exact reciprocal multiply   2: IEEE divide
+                        // 3: option "contract" — the coefficient form below (not bit-identical)
+    double a0, aW, aE, aS, aN;  // u' = a0 c + aW W + aE E + aS S + aN N, the same update as one 5-point stencil
 };
-Phys make_phys(double dx, double dy, double D, double dt, double vx, double vy);
+Phys make_phys(double dx, double dy, double D, double dt, double vx, double vy, bool contract = false);
 
 // kernel variants of the fused sweep (option "variant")
 enum { VAR_AUTO = 0, VAR_DPP = 1, VAR_LDS = 2, VAR_NAIVE = 3 };

@@ -154,7 +154,14 @@ int csim_stepper_tune(csim_stepper* s, double D, double dt, double vx, double vy
 int csim_stepper_sync(csim_stepper* s);
 int csim_stepper_minmax(csim_stepper* s, double out_min_max[2]);
 int csim_stepper_sum(csim_stepper* s, double* out);
-/* tuning / measurement knobs; unknown keys give CSIM_ERR_ARG.  Results never depend on them.
+/* tuning / measurement knobs; unknown keys give CSIM_ERR_ARG.  Results never depend on them, with ONE
+ * exception that is off by default:
+ *   "contract"       0 (default): every cell update is evaluated in the reference's own operation order
+ *                    without FMA contraction (src/diffusion.cpp:9-16, src/advection.cpp:13-33) -> results
+ *                    are bit-identical to the reference.  1 (opt-in): the same update as the 5-point
+ *                    stencil a0 c + aW W + aE E + aS S + aN N in FMA form (5 instead of 15 fp64
+ *                    operations per cell); rounding differs by a few ulp per step, L_inf vs the reference
+ *                    stays far below the 1e-10 tolerance (tests/test_gpu_contract.py).
  *   "fuse"           time steps per HBM pass: -1 auto (deepest the decomposition allows), 0/1 off, 2..6
  *   "variant"        single-step kernel family: 0 auto, 1 dpp, 2 lds, 3 naive
  *   "rows_per_chunk" rows one wavefront marches per launch (0 auto), "prefetch" (single-step kernel)
