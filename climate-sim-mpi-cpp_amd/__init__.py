@@ -58,6 +58,11 @@ class Decomp(C.Structure):
                     y_offset=self.y_offset)
 
 
+class Msg(C.Structure):
+    """struct csim_msg: one message of a halo exchange (peer rank, direction 0..7, doubles)."""
+    _fields_ = [("peer", C.c_int), ("dir", C.c_int), ("count", C.c_long)]
+
+
 def build(force: bool = False) -> str:
     """Compile csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
     if force or not os.path.exists(LIB_PATH):
@@ -97,6 +102,7 @@ def lib() -> C.CDLL:
         "csim_device_name": (i, [C.c_char_p, C.c_size_t]),
         "csim_safe_dt": (d, [d] * 5),
         "csim_decomp_init": (i, [i, i, i, i, C.POINTER(Decomp)]),
+        "csim_exchange_plan": (i, [C.POINTER(Decomp), i, C.POINTER(Msg), ip, C.POINTER(Msg), ip]),
         "csim_field_create": (i, [i, i, i, d, d, C.POINTER(vp)]),
         "csim_field_destroy": (i, [vp]),
         "csim_field_upload": (i, [vp, dp]),
@@ -206,6 +212,15 @@ def decomp_init(size, rank, nx_global, ny_global) -> Decomp:
     d = Decomp()
     _ck(lib().csim_decomp_init(size, rank, nx_global, ny_global, C.byref(d)))
     return d
+
+
+def exchange_plan(dec: Decomp, depth: int):
+    """(sends, recvs) of one halo exchange of this rank, each an ordered list of (peer, dir, count)."""
+    sends, recvs = (Msg * 8)(), (Msg * 8)()
+    ns, nr = C.c_int(0), C.c_int(0)
+    _ck(lib().csim_exchange_plan(C.byref(dec), depth, sends, C.byref(ns), recvs, C.byref(nr)))
+    return ([(m.peer, m.dir, m.count) for m in sends[:ns.value]],
+            [(m.peer, m.dir, m.count) for m in recvs[:nr.value]])
 
 
 class Field:

@@ -145,10 +145,7 @@ struct csim_stepper {
     int nbr8[8]{-1, -1, -1, -1, -1, -1, -1, -1};
     size_t cap2[8]{0, 0, 0, 0, 0, 0, 0, 0};  // staging capacity (faces of depth MAX_FUSE)
     // doubles in the face of direction d at depth H
-    size_t face_len(int d, int H) const {
-        return d < 2 ? static_cast<size_t>(H) * (ny + 2) : d < 4 ? static_cast<size_t>(H) * (nx + 2)
-                                                          : static_cast<size_t>(H) * H;
-    }
+    size_t face_len(int d, int H) const;
     double* send2[8]{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double* recv2[8]{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_edge2 = nullptr, ev_recv2 = nullptr;
@@ -190,6 +187,9 @@ struct csim_stepper {
     // whole-allocation pointer of a view
     double* base(double* view) const { return view - static_cast<size_t>(GHOST_EXTRA) * pitch; }
 };
+
+static size_t face_doubles(int d, int H, int nx, int ny);
+size_t csim_stepper::face_len(int d, int H) const { return face_doubles(d, H, nx, ny); }
 
 extern "C" {
 
@@ -256,6 +256,59 @@ int csim_decomp_init(int size, int rank, int nx_global, int ny_global, csim_deco
     d.y_offset = cy * by;
     CSIM_REQUIRE(d.nx_local > 0 && d.ny_local > 0, "more ranks than cells along an axis");
     *out = d;
+    return CSIM_OK;
+}
+
+// The 8 peers of a tile (L R B T BL BR TL TR): the four sides from the decomposition, a diagonal
+// only where both adjacent sides have neighbours.  A size-1 decomposition whose sides were pointed
+// at rank 0 is the self-linked test torus.
+static void neighbours8(const csim_decomp& dec, int nbr8[8]) {
+    for (int k = 0; k < 4; ++k) nbr8[k] = dec.nbr[k];
+    const int cx = dec.coords[0], cy = dec.coords[1], py = dec.dims[1];
+    auto diag = [&](int sx, int sy, int dx_, int dy_) {
+        if (dec.nbr[sx] < 0 || dec.nbr[sy] < 0) return -1;
+        return dec.size == 1 ? 0 : (cx + dx_) * py + (cy + dy_);
+    };
+    nbr8[4] = diag(CSIM_LEFT, CSIM_BOTTOM, -1, -1);
+    nbr8[5] = diag(CSIM_RIGHT, CSIM_BOTTOM, +1, -1);
+    nbr8[6] = diag(CSIM_LEFT, CSIM_TOP, -1, +1);
+    nbr8[7] = diag(CSIM_RIGHT, CSIM_TOP, +1, +1);
+}
+
+// doubles in the face of direction d at depth H on an nx x ny tile (depth 1: the interior span of an
+// edge line, reference src/halo.cpp:12-18; deeper: ghost entries ride along, corners are H x H blocks)
+static size_t face_doubles(int d, int H, int nx, int ny) {
+    if (H == 1) return d < 2 ? static_cast<size_t>(ny) : static_cast<size_t>(nx);
+    return d < 2 ? static_cast<size_t>(H) * (ny + 2) : d < 4 ? static_cast<size_t>(H) * (nx + 2)
+                                                       : static_cast<size_t>(H) * H;
+}
+
+// THE message order of one halo exchange — the only place it is decided (post_exchange and
+// post_exchange2 walk this plan).  Sends go out in direction order; receives are posted in
+// opposite-direction order, so that the k-th message a rank sends to a given peer is the k-th one
+// that peer expects from it even when one peer sits in several directions (2-wide process grids, the
+// self-linked torus): RCCL matches the sends and receives of a pair in posting order.
+int csim_exchange_plan(const csim_decomp* dec, int depth, csim_msg sends[8], int* nsend, csim_msg recvs[8],
+                       int* nrecv) {
+    CSIM_REQUIRE(dec && sends && nsend && recvs && nrecv, "null argument");
+    CSIM_REQUIRE(depth >= 1 && depth <= MAX_FUSE, "depth must be 1..6");
+    static const int recv_order1[4] = {CSIM_RIGHT, CSIM_LEFT, CSIM_TOP, CSIM_BOTTOM};
+    static const int recv_order8[8] = {1, 0, 3, 2, 7, 6, 5, 4};
+    int nbr8[8];
+    neighbours8(*dec, nbr8);
+    const int ndir = depth == 1 ? 4 : 8;
+    const int* order = depth == 1 ? recv_order1 : recv_order8;
+    int ns = 0, nr = 0;
+    for (int d = 0; d < ndir; ++d)
+        if (nbr8[d] >= 0)
+            sends[ns++] = csim_msg{nbr8[d], d, static_cast<long>(face_doubles(d, depth, dec->nx_local, dec->ny_local))};
+    for (int q = 0; q < ndir; ++q) {
+        const int d = order[q];
+        if (nbr8[d] >= 0)
+            recvs[nr++] = csim_msg{nbr8[d], d, static_cast<long>(face_doubles(d, depth, dec->nx_local, dec->ny_local))};
+    }
+    *nsend = ns;
+    *nrecv = nr;
     return CSIM_OK;
 }
 
@@ -461,19 +514,7 @@ int csim_stepper_create(const csim_decomp* dec, double dx, double dy, const int 
         const int min_tile = s->multi ? std::min(bx, by) : MAX_FUSE;
         s->fuse_cap = std::max(1, std::min(MAX_FUSE, min_tile));
     }
-    // diagonal peers (only where both adjacent sides have neighbours)
-    for (int k = 0; k < 4; ++k) s->nbr8[k] = dec->nbr[k];
-    {
-        const int cx = dec->coords[0], cy = dec->coords[1], py = dec->dims[1];
-        auto diag = [&](int sx, int sy, int dx_, int dy_) {
-            if (dec->nbr[sx] < 0 || dec->nbr[sy] < 0) return -1;
-            return dec->size == 1 ? 0 : (cx + dx_) * py + (cy + dy_);
-        };
-        s->nbr8[4] = diag(CSIM_LEFT, CSIM_BOTTOM, -1, -1);
-        s->nbr8[5] = diag(CSIM_RIGHT, CSIM_BOTTOM, +1, -1);
-        s->nbr8[6] = diag(CSIM_LEFT, CSIM_TOP, -1, +1);
-        s->nbr8[7] = diag(CSIM_RIGHT, CSIM_TOP, +1, +1);
-    }
+    neighbours8(*dec, s->nbr8);  // diagonal peers only where both adjacent sides have neighbours
     for (int d = 0; d < 8 && e == hipSuccess; ++d) {
         if (s->nbr8[d] < 0) continue;
         s->cap2[d] = s->face_len(d, MAX_FUSE);
@@ -648,47 +689,27 @@ int csim_stepper_init_gaussian(csim_stepper* s, double A, double sigma_frac, dou
     return CSIM_OK;
 }
 
-// one grouped RCCL exchange of the staged edge lines (replaces the ≤8 MPI requests of reference
-// src/halo.cpp:28-46).  Sends are posted left,right,bottom,top and receives right,left,top,bottom
-// so that message order also matches when both x- (or y-) neighbours are the same peer.
-static int post_exchange(csim_stepper* s, hipStream_t st) {
+// one grouped RCCL exchange (replaces the <= 8 MPI requests + MPI_Waitall of reference src/halo.cpp:28-46):
+// depth 1 = the staged edge lines of the four sides, depth 2..6 = the deep faces of all eight
+// directions (diagonal ranks are direct xGMI peers too), in the order csim_exchange_plan fixes.
+static int post_plan(csim_stepper* s, int depth, hipStream_t st) {
     if (!s->comm) return fail(CSIM_ERR_STATE, "halo exchange needs csim_stepper_comm_init first");
-    static const int recv_order[4] = {CSIM_RIGHT, CSIM_LEFT, CSIM_TOP, CSIM_BOTTOM};
+    csim_msg sends[8], recvs[8];
+    int ns = 0, nr = 0;
+    int rc = csim_exchange_plan(&s->dec, depth, sends, &ns, recvs, &nr);
+    if (rc) return rc;
+    double* const* sbuf = depth == 1 ? s->send : s->send2;
+    double* const* rbuf = depth == 1 ? s->recv : s->recv2;
     CSIM_NCCL(ncclGroupStart());
-    for (int k = 0; k < 4; ++k) {
-        if (s->phys[k]) continue;
-        const size_t n = static_cast<size_t>(k < 2 ? s->ny : s->nx);
-        CSIM_NCCL(ncclSend(s->send[k], n, ncclDouble, s->dec.nbr[k], s->comm, st));
-    }
-    for (int q = 0; q < 4; ++q) {
-        const int k = recv_order[q];
-        if (s->phys[k]) continue;
-        const size_t n = static_cast<size_t>(k < 2 ? s->ny : s->nx);
-        CSIM_NCCL(ncclRecv(s->recv[k], n, ncclDouble, s->dec.nbr[k], s->comm, st));
-    }
+    for (int k = 0; k < ns; ++k)
+        CSIM_NCCL(ncclSend(sbuf[sends[k].dir], static_cast<size_t>(sends[k].count), ncclDouble, sends[k].peer, s->comm, st));
+    for (int k = 0; k < nr; ++k)
+        CSIM_NCCL(ncclRecv(rbuf[recvs[k].dir], static_cast<size_t>(recvs[k].count), ncclDouble, recvs[k].peer, s->comm, st));
     CSIM_NCCL(ncclGroupEnd());
     return CSIM_OK;
 }
-
-// the same for the depth-2 faces of the two-steps-per-pass sweep: up to 8 peers in ONE group
-// (diagonal ranks are direct xGMI peers too).  Sends go out in direction order, receives are
-// posted in opposite-direction order, so per-peer message order matches even when one peer sits
-// in several directions (a 2-wide process grid, or the self-linked test torus).
-static int post_exchange2(csim_stepper* s, int H, hipStream_t st) {
-    if (!s->comm) return fail(CSIM_ERR_STATE, "halo exchange needs csim_stepper_comm_init first");
-    static const int recv_order[8] = {1, 0, 3, 2, 7, 6, 5, 4};
-    CSIM_NCCL(ncclGroupStart());
-    for (int d = 0; d < 8; ++d)
-        if (s->nbr8[d] >= 0)
-            CSIM_NCCL(ncclSend(s->send2[d], s->face_len(d, H), ncclDouble, s->nbr8[d], s->comm, st));
-    for (int q = 0; q < 8; ++q) {
-        const int d = recv_order[q];
-        if (s->nbr8[d] >= 0)
-            CSIM_NCCL(ncclRecv(s->recv2[d], s->face_len(d, H), ncclDouble, s->nbr8[d], s->comm, st));
-    }
-    CSIM_NCCL(ncclGroupEnd());
-    return CSIM_OK;
-}
+static int post_exchange(csim_stepper* s, hipStream_t st) { return post_plan(s, 1, st); }
+static int post_exchange2(csim_stepper* s, int H, hipStream_t st) { return post_plan(s, H, st); }
 
 // halos of the CURRENT field: pack its edge lines, exchange, leave them staged in recv[]
 static int refresh_halos(csim_stepper* s) {

@@ -75,6 +75,22 @@ double csim_safe_dt(double dx, double dy, double vx, double vy, double D);
 /* reference src/decomp.cpp:5-34  Decomp2D::init(comm, nx_global, ny_global), MPI-free:
  * MPI_Dims_create(size,2) + MPI_Cart_create(periods 0,0, reorder 0) are re-derived. */
 int csim_decomp_init(int size, int rank, int nx_global, int ny_global, csim_decomp* out);
+/* The halo exchange of one rank as an ordered message list (pure host arithmetic, no GPU): what
+ * the stepper posts inside ONE ncclGroupStart/End — replaces the <= 8 MPI_Isend/Irecv + MPI_Waitall of
+ * reference src/halo.cpp:28-46.  depth 1: the four edge lines (ny / nx doubles, interior span);
+ * depth 2..6 (fused passes): faces of that depth in 8 directions 0..7 = left, right, bottom, top,
+ * bottom-left, bottom-right, top-left, top-right (depth*(ny+2), depth*(nx+2), depth*depth doubles).
+ * sends[k].dir = the direction the face leaves in; recvs[k].dir = the direction it arrives FROM.  RCCL
+ * matches the messages of a pair of ranks in posting order, so for every pair (a, b) the k-th send
+ * of a to b must be the k-th receive b posts for a: tests/test_exchange_plan.py checks exactly that
+ * for every rank pair of 2x1 ... 4x2 process grids at every depth. */
+typedef struct csim_msg {
+    int peer;    /* rank */
+    int dir;     /* 0..7 */
+    long count;  /* doubles */
+} csim_msg;
+int csim_exchange_plan(const csim_decomp* dec, int depth, csim_msg sends[8], int* nsend, csim_msg recvs[8],
+                       int* nrecv);
 
 /* ---- Field (reference include/field.hpp:5-21, src/field.cpp:6-31) ------------------------ */
 int csim_field_create(int nx, int ny, int halo, double dx, double dy, csim_field** out); /* zero-filled */

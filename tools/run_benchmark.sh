@@ -6,18 +6,19 @@
 # Needs climate_sim_hip_mpi (make -C climate-sim-mpi-cpp_amd/driver mpi) and mpirun for counts > 1;
 # count 1 uses climate_sim_hip.  Unlike the reference script, physics is switched on (its
 # defaults run D = v = 0) and snapshots are off in the timed run (--no-output).
+# DRV / MPIRUN / OUT can be overridden (tests/test_scaling_tools.py runs the script against a stand-in driver).
 # Output: bench/results/<mode>.csv with ranks, grid, seconds, Mcell-updates/s, speedup,
 # efficiency and the Karp-Flatt serial fraction.
 set -euo pipefail
 MODE=${1:-strong}; shift || true
 COUNTS=("$@"); [ ${#COUNTS[@]} -eq 0 ] && COUNTS=(1)
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-DRV=$ROOT/climate-sim-mpi-cpp_amd/driver
+DRV=${DRV:-$ROOT/climate-sim-mpi-cpp_amd/driver}
 MPIRUN=${MPIRUN:-/opt/conda/bin/mpirun}
 NX=${NX:-16384}; NY=${NY:-16384}; STEPS=${STEPS:-200}
 TILE=${TILE:-8192}
 PHYS="--D=0.05 --vx=0.5 --vy=0.25 --dt=0.1"
-OUT=$ROOT/bench/results; mkdir -p "$OUT"
+OUT=${OUT:-$ROOT/bench/results}; mkdir -p "$OUT"
 CSV=$OUT/$MODE.csv
 echo "ranks,nx,ny,steps,total_max_s,mcell_updates_per_s,speedup,efficiency,karp_flatt" > "$CSV"
 T1=""
