@@ -300,9 +300,10 @@ def main():
             sys.stderr.write(f"[bench] rank {rank}: falling back to host-staged halos over gloo ({why})\n")
             st.set_option("external_halo", 1)
     for key, val in (("variant", args.variant), ("rows_per_chunk", args.rows_per_chunk),
-                     ("prefetch", args.prefetch), ("overlap", 0 if args.no_overlap else 1),
-                     ("fuse", args.fuse)):
+                     ("prefetch", args.prefetch), ("fuse", args.fuse)):
         st.set_option(key, val)
+    if args.no_overlap:
+        st.set_option("overlap", 0)   # otherwise the stepper's default (3 where the device offers it, else 1)
     if args.contract:
         st.set_option("contract", args.contract)
     if args.lds_bytes:
@@ -358,8 +359,13 @@ def main():
     # non-overlapped timings anyway)
     exchange_modes = None
     if multi and halo == "rccl" and not args.no_overlap and args.overlap_mode < 0:
-        cands = [("overlap-1 frame first, exchange under the bulk sweep", 1, None),
+        cands = [("overlap-1 frame launch first, exchange under the bulk launch", 1, None),
                  ("overlap-0 exchange not overlapped", 0, None)]
+        try:  # frame + bulk in one launch, comm stream released by a flag the frame wavefronts publish
+            st.set_option("overlap", 3)
+            cands.insert(0, ("overlap-3 frame and bulk in one launch, exchange released by an in-kernel flag", 3, None))
+        except Exception:  # noqa: BLE001  (no hipStreamWaitValue64 / signal memory on this device)
+            pass
         if os.environ.get("CSIM_BENCH_TRY_OVERLAP2") == "1":
             # the three-stream schedule has only ever run on the self-linked torus of one GPU: opt-in
             cands += [("overlap-2 frame stream beside the bulk, bulk capped at 3 workgroups/CU", 2, 41984),
@@ -495,11 +501,15 @@ def main():
                     "count but change the bits)",
         }
         if valu:
-            insts = valu["SQ_INSTS_VALU"]
+            # the counters are of the whole-field launch on valu["nx"] x valu["ny"]: per cell they do not
+            # depend on the grid (same strips, same chunking overheads to within a per cent)
+            insts = valu["SQ_INSTS_VALU"] * local_cells / (float(valu["nx"]) * float(valu["ny"]))
             fp64_share = valu.get("fp64_share", 180.0 / 204.0)
             executed = insts * 64 * fp64_share / secs / 1e12
             roofline_valu.update(
                 insts_per_launch=insts,
+                insts_scaled_from_grid=None if (valu["nx"], valu["ny"]) == (dec.nx_local, dec.ny_local)
+                else f"{valu['nx']}x{valu['ny']}",
                 executed_fp64_tops=executed,
                 executed_frac=executed / FP64_VALU_PEAK_TOPS,
                 redundancy_executed_over_useful=executed / useful_tops,

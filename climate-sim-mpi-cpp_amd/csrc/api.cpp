@@ -149,6 +149,13 @@ struct csim_stepper {
     double* send2[8]{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double* recv2[8]{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_edge2 = nullptr, ev_recv2 = nullptr;
+    // overlap mode 3: frame + bulk in one launch; the frame wavefronts publish the pass number in `frame_flag`
+    // (signal memory) and the comm stream waits on it with hipStreamWaitValue64
+    unsigned* frame_counter = nullptr;
+    unsigned long long* frame_flag = nullptr;
+    unsigned long long pass_no = 0;
+    int frame_fence = 0, frame_prio = 1;  // experiment switches of mode 3, see FrameSync
+    int reserve_cus = 0;                  // CUs masked out of the compute stream (option "reserve_cus")
     // asynchronous snapshot of the interior (device staging copy + pinned host buffer + I/O stream)
     double* snap_d = nullptr;
     double* snap_h = nullptr;
@@ -159,8 +166,9 @@ struct csim_stepper {
     int fuse_cap = 1;     // deepest pass every rank of the decomposition can run (same on all ranks)
     int faces_depth = 0;  // recv2[] holds the neighbours' faces of `cur` of this depth (0 = none)
     SweepCfg cfg;
-    int overlap = 1;        // 0: exchange serial; 1: frame, then bulk hiding the exchange; 2: + frame of the next
-                            // pass concurrent with the bulk on its own stream (see pass_fused_concurrent)
+    int overlap = 1;        // 0: exchange serial; 1: frame launch, then bulk launch hiding the exchange; 2: + frame of
+                            // the next pass concurrent with the bulk on its own stream (see pass_fused_concurrent);
+                            // 3 (default where signal memory exists): frame and bulk in ONE launch, see pass_fused
     bool frame_async = false;  // the last pass left frame work on s_frame that s_comp has not joined yet
     bool ring_ok = false;      // single rank without a Neumann side: the ghost ring (Dirichlet value / untouched
                                // Periodic ghosts) is constant and both buffers already hold it — no more ghost fills
@@ -535,6 +543,26 @@ int csim_stepper_create(const csim_decomp* dec, double dx, double dy, const int 
         ok(hipEventCreateWithFlags(&s->ev_edge2, hipEventDisableTiming)) &&
             ok(hipEventCreateWithFlags(&s->ev_recv2, hipEventDisableTiming));
     }
+    if (e == hipSuccess && s->multi) {
+        ok(hipMalloc(reinterpret_cast<void**>(&s->frame_counter), sizeof(unsigned))) &&
+            ok(hipMemset(s->frame_counter, 0, sizeof(unsigned)));
+        // signal memory: absent or refused -> mode 3 is simply not offered (set_option reports it)
+        if (e == hipSuccess) {
+            int can = 0;
+            int dev = 0;
+            if (hipGetDevice(&dev) == hipSuccess &&
+                hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, dev) == hipSuccess && can) {
+                void* p = nullptr;
+                if (hipExtMallocWithFlags(&p, 8, hipMallocSignalMemory) == hipSuccess) {
+                    s->frame_flag = static_cast<unsigned long long*>(p);
+                    *s->frame_flag = 0;  // host-visible
+                    s->overlap = 3;      // the default schedule where the device offers it
+                } else {
+                    (void)hipGetLastError();
+                }
+            }
+        }
+    }
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) {
         s->cur = s->buf[0] + static_cast<size_t>(GHOST_EXTRA) * s->pitch;
@@ -570,6 +598,8 @@ int csim_stepper_destroy(csim_stepper* s) {
         if (s->send2[d]) (void)hipFree(s->send2[d]);
         if (s->recv2[d]) (void)hipFree(s->recv2[d]);
     }
+    if (s->frame_counter) (void)hipFree(s->frame_counter);
+    if (s->frame_flag) (void)hipFree(s->frame_flag);
     if (s->ev_edge2) (void)hipEventDestroy(s->ev_edge2);
     if (s->ev_recv2) (void)hipEventDestroy(s->ev_recv2);
     if (s->ev_edge) (void)hipEventDestroy(s->ev_edge);
@@ -951,12 +981,13 @@ static int pass_single(csim_stepper* s, const Phys& p, const GhostArgs& g) {
 // computed first and the comm stream packs and exchanges their depth-next_T faces while the bulk
 // of the sweep is still running.
 static hipError_t launch_fused(csim_stepper* s, const Phys& p, const int kind[4], int T, int part,
-                               hipStream_t st, bool final_pass = false, int lds_bytes = 0) {
+                               hipStream_t st, bool final_pass = false, int lds_bytes = 0,
+                               const FrameSync* sync = nullptr) {
     SweepCfg cfg = s->cfg;
     if (lds_bytes > 0) cfg.lds_bytes = lds_bytes;
     cfg.rows_used = &s->last_rows;
     return launch_sweepO(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, cfg, kind, s->bc_value, T, part, st,
-                         final_pass ? s->fin : nullptr);
+                         final_pass ? s->fin : nullptr, sync);
 }
 
 // s_comp waits for the frame work a concurrent pass left on s_frame (no-op otherwise)
@@ -1049,19 +1080,33 @@ static int pass_fused(csim_stepper* s, const Phys& p, int T, int next_T, bool fi
     int rc = prof_begin(s, T);
     if (rc) return rc;
     if (rccl && s->overlap && next_T >= 2) {
-        // FRAME tiles first (thin tiles along the four edges, ~15 us), then the BULK on the same
-        // stream; as soon as the frame is done the comm stream packs the NEXT pass's faces from it
-        // and runs the exchange, which the bulk hides
-        CSIM_HIP(launch_fused(s, p, kind, T, 1, s->s_comp));
-        CSIM_HIP(hipEventRecord(s->ev_edge2, s->s_comp));
-        CSIM_HIP(hipStreamWaitEvent(s->s_comm, s->ev_edge2, 0));
+        if (s->overlap == 3 && s->frame_flag) {
+            // ONE launch: the frame tiles are the first blocks of the grid, the bulk tiles fill the rest of
+            // the chip at once; the last frame wavefront publishes this pass's number and the comm stream,
+            // parked on that value by the command processor, starts the exchange under the running kernel
+            FrameSync fs;
+            fs.counter = s->frame_counter;
+            fs.flag = s->frame_flag;
+            fs.pass = ++s->pass_no;
+            fs.fence = s->frame_fence;
+            fs.prio = s->frame_prio;
+            CSIM_HIP(launch_fused(s, p, kind, T, 3, s->s_comp, false, 0, &fs));
+            CSIM_HIP(hipStreamWaitValue64(s->s_comm, s->frame_flag, fs.pass, hipStreamWaitValueGte, ~0ull));
+        } else {
+            // FRAME tiles first (thin tiles along the four edges, ~15 us), then the BULK on the same
+            // stream; as soon as the frame is done the comm stream packs the NEXT pass's faces from it
+            // and runs the exchange, which the bulk hides
+            CSIM_HIP(launch_fused(s, p, kind, T, 1, s->s_comp));
+            CSIM_HIP(hipEventRecord(s->ev_edge2, s->s_comp));
+            CSIM_HIP(hipStreamWaitEvent(s->s_comm, s->ev_edge2, 0));
+        }
         long comm_slot = -1;
         rc = prof_start(s, csim_stepper::PROF_COMM, s->s_comm, &comm_slot);
         if (rc) return rc;
         CSIM_HIP(launch_halo2_pack(s->nxt, s->nx, s->ny, s->pitch, next_T, s->send2, s->s_comm));
         rc = post_exchange2(s, next_T, s->s_comm);
         if (rc) return rc;
-        if (s->overlap == 1) {
+        if (s->overlap == 1 || s->overlap == 3) {
             // the comm stream goes on to prepare the next pass — unpack of the faces into the new
             // field's halo cells, ghost fill of both buffers' rings — while the bulk is still
             // sweeping: those cells are disjoint from everything the bulk reads or writes, and
@@ -1073,7 +1118,7 @@ static int pass_fused(csim_stepper* s, const Phys& p, int T, int next_T, bool fi
         rc = prof_stop(s, comm_slot, s->s_comm);
         if (rc) return rc;
         CSIM_HIP(hipEventRecord(s->ev_recv2, s->s_comm));
-        CSIM_HIP(launch_fused(s, p, kind, T, 2, s->s_comp));
+        if (!(s->overlap == 3 && s->frame_flag)) CSIM_HIP(launch_fused(s, p, kind, T, 2, s->s_comp));
         s->faces_depth = next_T;
     } else {
         CSIM_HIP(launch_fused(s, p, kind, T, 0, s->s_comp, final_pass));
@@ -1260,8 +1305,42 @@ int csim_stepper_set_option(csim_stepper* s, const char* key, long value) {
     } else if (k == "xcd_swizzle") {
         s->cfg.xcd_swizzle = value != 0;
     } else if (k == "overlap") {
-        CSIM_REQUIRE(value >= 0 && value <= 2, "overlap must be 0, 1 or 2");
+        CSIM_REQUIRE(value >= 0 && value <= 3, "overlap must be 0, 1, 2 or 3");
+        if (value == 3 && s->multi && !s->frame_flag)
+            return fail(CSIM_ERR_STATE, "overlap 3 needs hipStreamWaitValue64 / signal memory, which this device or runtime refused");
         s->overlap = static_cast<int>(value);
+    } else if (k == "reserve_cus") {
+        // the compute stream is re-created with a CU mask that leaves `value` CUs (spread evenly over the
+        // mask) to everything else — the RCCL kernel and the small pack / unpack / ghost kernels of the comm
+        // stream then find idle CUs instead of sharing SIMDs with the VALU-bound sweep.  0 = whole chip.
+        CSIM_REQUIRE(value >= 0 && value <= 64, "reserve_cus must be 0..64");
+        int dev = 0;
+        CSIM_HIP(hipGetDevice(&dev));
+        hipDeviceProp_t prop;
+        CSIM_HIP(hipGetDeviceProperties(&prop, dev));
+        const int ncu = prop.multiProcessorCount;
+        CSIM_HIP(hipStreamSynchronize(s->s_comp));
+        hipStream_t fresh = nullptr;
+        if (value == 0) {
+            CSIM_HIP(hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking));
+        } else {
+            std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+            for (int cu = 0; cu < ncu; ++cu) mask[cu / 32] |= 1u << (cu % 32);
+            const int nres = static_cast<int>(value);
+            for (int k2 = 0; k2 < nres; ++k2) {
+                const int cu = static_cast<int>((static_cast<long>(k2) * ncu) / nres + ncu / (2 * nres));
+                mask[cu / 32] &= ~(1u << (cu % 32));
+            }
+            CSIM_HIP(hipExtStreamCreateWithCUMask(&fresh, static_cast<uint32_t>(mask.size()), mask.data()));
+        }
+        CSIM_HIP(hipStreamDestroy(s->s_comp));
+        s->s_comp = fresh;
+        s->reserve_cus = static_cast<int>(value);
+    } else if (k == "frame_fence") {
+        CSIM_REQUIRE(value >= 0 && value <= 2, "frame_fence must be 0..2");
+        s->frame_fence = static_cast<int>(value);
+    } else if (k == "frame_prio") {
+        s->frame_prio = value != 0;
     } else if (k == "bulk_lds") {
         CSIM_REQUIRE(value >= 0 && value <= 65536, "bulk_lds must be 0..65536");
         s->bulk_lds = static_cast<int>(value);
@@ -1310,6 +1389,7 @@ int csim_stepper_get_option(const csim_stepper* s, const char* key, long* value)
     else if (k == "external_halo") *value = s->external;
     else if (k == "fuse") *value = s->fuse;
     else if (k == "contract") *value = s->contract;
+    else if (k == "reserve_cus") *value = s->reserve_cus;
     else if (k == "autotune") *value = s->autotune;
     else if (k == "profile") *value = s->profile;
     else return fail(CSIM_ERR_ARG, "unknown option: " + k);

@@ -78,9 +78,21 @@ hipError_t launch_sweep(const double* in, double* out, int nx, int ny, int pitch
 // neighbour sides; part: 0 = every tile, 1 = frame tiles only, 2 = all but the frame tiles.
 // fin_lines (last pass of a run, all four or nullptr): per side the level T-1 line the final ghost
 // fill needs — see FinLines in kernels.hip
+// part 3 = frame and bulk in ONE grid (frame tiles dispatched first); with `sync` the frame wavefronts
+// count themselves on sync->counter and the last one stores sync->pass into sync->flag (signal memory a
+// stream can wait on with hipStreamWaitValue64), see k_sweepO_dpp
+struct FrameSync {
+    unsigned* counter = nullptr;
+    unsigned long long* flag = nullptr;
+    unsigned long long pass = 0;
+    unsigned nframe = 0;  // filled in by the launcher
+    int fence = 0;        // 0 write-through result stores + drain (default), 1 plain stores + agent-scope fence per
+                          // wavefront (slow), 2 plain stores, drain only (timing experiments: NOT safe)
+    int prio = 1;         // frame wavefronts raise their issue priority
+};
 hipError_t launch_sweepO(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
                          const SweepCfg& cfg, const int kind[4], double value, int T, int part,
-                         hipStream_t st, double* const fin_lines[4] = nullptr);
+                         hipStream_t st, double* const fin_lines[4] = nullptr, const FrameSync* sync = nullptr);
 constexpr int MAX_FUSE = 6;       // deepest temporal blocking
 constexpr int GHOST_EXTRA = 5;    // device-only ghost layers beyond the reference's one (= MAX_FUSE-1)
 // faces of depth H = 2..6 (8 directions: L R B T BL BR TL TR; nullptr = no neighbour there);

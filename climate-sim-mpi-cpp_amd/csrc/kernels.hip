@@ -122,6 +122,19 @@ __device__ __forceinline__ int xcd_remap(int b, int nb, int enable) {
     return xcd < rem ? xcd * (per + 1) + q : rem * (per + 1) + (xcd - rem) * per + q;
 }
 
+// write-through flavour (agent-scope relaxed atomic stores, `global_store ... sc1`): the values are in
+// memory, visible to every XCD, once the wavefront's s_waitcnt vmcnt(0) returns — no L2 write-back
+// (buffer_wbl2) needed.  Used by the frame tiles of a merged launch, whose outputs later kernels on
+// another stream read while this kernel is still running.
+__device__ __forceinline__ void store_pair_wt(double* dst, double ox, double oy, int nvalid) {
+    if (nvalid >= 1)
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), static_cast<unsigned long long>(__double_as_longlong(ox)),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (nvalid >= 2)
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst + 1), static_cast<unsigned long long>(__double_as_longlong(oy)),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ void store_pair(double* dst, double ox, double oy, int nvalid) {
     if (nvalid >= 2) {
         *reinterpret_cast<double2*>(dst) = make_double2(ox, oy);
@@ -286,7 +299,7 @@ template <int DIV, int T, bool EDGE, int SX, int SY>
 __device__ __forceinline__ void sweepO_march(const double* __restrict__ in, double* __restrict__ out,
                                              int nx, int ny, int pitch, int jb, int je, int g0, int lane,
                                              int kl, int kr, const Phys& p, const Bc2& bc,
-                                             const FinLines& fin, bool fin_l, bool fin_r) {
+                                             const FinLines& fin, bool fin_l, bool fin_r, bool wt) {
     constexpr int TP = OverlapGeom<T>::TP;
     constexpr int STRIDE = OverlapGeom<T>::STRIDE;
     // this lane's two columns, 0-based interior index (-1 = left ghost, nx = right ghost)
@@ -404,7 +417,12 @@ __device__ __forceinline__ void sweepO_march(const double* __restrict__ in, doub
                         }
                         L[l][u % 3] = o;
                     } else if (rho >= jb && rho <= je && out_lane) {
-                        store_pair(out + static_cast<ptrdiff_t>(rho) * pitch + xoff, o.x, o.y, nvalid);
+                        if (wt) {  // wave-uniform: frame tile of a merged launch
+                            keep_branch();
+                            store_pair_wt(out + static_cast<ptrdiff_t>(rho) * pitch + xoff, o.x, o.y, nvalid);
+                        } else {
+                            store_pair(out + static_cast<ptrdiff_t>(rho) * pitch + xoff, o.x, o.y, nvalid);
+                        }
                     }
                 }
                 L0[u % 6] = load(min(r + 5, last_row));  // row r-1 is dead: its slot takes row r+5
@@ -431,15 +449,19 @@ struct TileRegion {
     int j0, j1, ry;     // rows j0 .. j1 in chunks of ry
 };
 struct Tiling {
-    TileRegion r[4];
+    TileRegion r[5];
     int nregions, ntiles;
+    // merged launch (frame + bulk in one grid): tiles [0, frame_tiles) are the frame, owned by blocks
+    // [0, frame_blocks) in plain order so that they are dispatched first and spread over all XCDs; the
+    // bulk tiles follow from tile 4 * frame_blocks on, XCD-remapped among themselves.  0 = not merged.
+    int frame_tiles, frame_blocks;
 };
 
 template <int DIV, int T, int SX, int SY>
 __global__ __launch_bounds__(256) void k_sweepO_dpp(const double* __restrict__ in,
                                                     double* __restrict__ out, int nx, int ny,
                                                     int pitch, int nstrips, Tiling tl, int swz,
-                                                    Phys p, Bc2 bc, FinLines fin) {
+                                                    Phys p, Bc2 bc, FinLines fin, FrameSync fs) {
     constexpr int TP = OverlapGeom<T>::TP;
     constexpr int STRIDE = OverlapGeom<T>::STRIDE;
     const int lane = threadIdx.x & 63;
@@ -449,11 +471,24 @@ __global__ __launch_bounds__(256) void k_sweepO_dpp(const double* __restrict__ i
 #ifdef CSIM_TRACE
     WaveTrace trace_scope(blockIdx.x * 4 + wave, lane);
 #endif
-    const int tile = xcd_remap(blockIdx.x, gridDim.x, swz) * 4 + wave;
+    int tile;
+    bool frame_tile = false;
+    if (tl.frame_blocks > 0) {
+        const int b = blockIdx.x;
+        if (b < tl.frame_blocks) {
+            tile = 4 * b + wave;
+            if (tile >= tl.frame_tiles) return;  // padding of the last frame block
+            frame_tile = true;
+        } else {
+            tile = tl.frame_tiles + xcd_remap(b - tl.frame_blocks, gridDim.x - tl.frame_blocks, swz) * 4 + wave;
+        }
+    } else {
+        tile = xcd_remap(blockIdx.x, gridDim.x, swz) * 4 + wave;
+    }
     if (tile >= tl.ntiles) return;  // wave-uniform
     int t0 = 0, strip0 = tl.r[0].strip0, nstrip = tl.r[0].nstrip, j0 = tl.r[0].j0, j1 = tl.r[0].j1, ry = tl.r[0].ry;
 #pragma unroll
-    for (int q = 1; q < 4; ++q)
+    for (int q = 1; q < 5; ++q)
         if (q < tl.nregions && tile >= tl.r[q - 1].t_end) {
             t0 = tl.r[q - 1].t_end;
             strip0 = tl.r[q].strip0, nstrip = tl.r[q].nstrip, j0 = tl.r[q].j0, j1 = tl.r[q].j1, ry = tl.r[q].ry;
@@ -473,14 +508,40 @@ __global__ __launch_bounds__(256) void k_sweepO_dpp(const double* __restrict__ i
     const bool fin_frame = fin.line[CSIM_BOTTOM] != nullptr && (first || last || jb == 1 || je == ny);
     const bool edge = kl != 3 || kr != 3 || (bc.kind[CSIM_BOTTOM] != 3 && jb - (T - 1) < 1) ||
                       (bc.kind[CSIM_TOP] != 3 && je + (T - 1) > ny) || fin_frame;
+    if (frame_tile && fs.prio) __builtin_amdgcn_s_setprio(3);  // the faces wait for these: issue ahead of the co-resident bulk
+    const bool wt = frame_tile && fs.flag != nullptr && fs.fence == 0;
     if (edge) {
         // The edge body carries a few scalar tests and branches per level, so its wavefronts have
         // the longest latency per row and would finish last, leaving the rest of the chip idle
         // (29 % of a 4096 x 8192 launch, tools/wavetrace.hip): give them issue priority.
         __builtin_amdgcn_s_setprio(3);
-        sweepO_march<DIV, T, true, SX, SY>(in, out, nx, ny, pitch, jb, je, g0, lane, kl, kr, p, bc, fin, first, last);
+        sweepO_march<DIV, T, true, SX, SY>(in, out, nx, ny, pitch, jb, je, g0, lane, kl, kr, p, bc, fin, first, last, wt);
     } else
-        sweepO_march<DIV, T, false, SX, SY>(in, out, nx, ny, pitch, jb, je, g0, lane, kl, kr, p, bc, fin, false, false);
+        sweepO_march<DIV, T, false, SX, SY>(in, out, nx, ny, pitch, jb, je, g0, lane, kl, kr, p, bc, fin, false, false, wt);
+    if (frame_tile && fs.flag) {
+        // Merged launch: the comm stream is parked on `flag` (hipStreamWaitValue64) and goes on to pack and
+        // send the next pass's faces as soon as EVERY frame tile is in memory — while this very kernel is
+        // still sweeping the bulk.  The consumers are later kernels on another stream and may run on any XCD,
+        // so a frame tile's outputs must be in memory, not in this XCD's write-back L2, before it counts
+        // itself: its result stores are write-through (store_pair_wt) and only have to be drained here.  (An
+        // agent-scope release fence, i.e. buffer_wbl2 per wavefront, also works but writes back the dirty
+        // output lines of the whole bulk each time: measured +40 us per 165 us pass; kept as fence = 1.)  The
+        // wavefront that completes the count re-arms the counter and publishes the pass number (system scope:
+        // the waiting side reads it through the command processor).
+        if (fs.fence == 0)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (fs.fence == 1)
+            __threadfence();
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // experiment only: plain stores drained, NOT written back
+        if (lane == 0) {
+            const unsigned done = atomicAdd(fs.counter, 1u);
+            if (done == fs.nframe - 1) {
+                atomicExch(fs.counter, 0u);
+                __hip_atomic_store(fs.flag, fs.pass, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
 }
 
 // -------------------------------------------------------------------------------------------
@@ -972,7 +1033,8 @@ static hipError_t sweep_div(const double* in, double* out, int nx, int ny, int p
 
 template <int DIV, int T>
 static hipError_t sweepO_div(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
-                             const SweepCfg& cfg, const Bc2& bc, const FinLines& fin, int part, hipStream_t st) {
+                             const SweepCfg& cfg, const Bc2& bc, const FinLines& fin, int part, hipStream_t st,
+                             FrameSync fs) {
     constexpr int STRIDE = OverlapGeom<T>::STRIDE;
     const int nstrips = cdiv(nx, STRIDE);
     int ry = cfg.rows_per_chunk;
@@ -1005,23 +1067,38 @@ static hipError_t sweepO_div(const double* in, double* out, int nx, int ny, int 
         tl.ntiles += nstrip * cdiv(j1 - j0 + 1, rows);
         r.t_end = tl.ntiles;
     };
-    if (part == 0 || (part == 1 && !split)) {
+    if (part == 0 || ((part == 1 || part == 3) && !split)) {
         add(0, nstrips, 1, ny, ry);
-    } else if (part == 1) {
+    } else if (part == 1 || part == 3) {
         add(0, nstrips, 1, hf, hf);
         add(0, nstrips, ny - hf + 1, ny, hf);
         add(0, 1, hf + 1, ny - hf, hf);
         add(nstrips - nright, nright, hf + 1, ny - hf, hf);
-    } else if (split) {
-        add(1, nstrips - 1 - nright, hf + 1, ny - hf, std::min(ry, ny - 2 * hf));
     }
-    if (tl.ntiles == 0) return hipSuccess;  // part 2 of a field that is all frame
-    const dim3 grid(cdiv(tl.ntiles, 4)), block(256);
+    int nblocks;
+    if (part == 3) {  // merged launch: the frame tiles above, then the bulk in the same grid
+        tl.frame_tiles = tl.ntiles;
+        tl.frame_blocks = cdiv(tl.ntiles, 4);
+        fs.nframe = static_cast<unsigned>(tl.frame_tiles);
+        int bulk_tiles = 0;
+        if (split) {
+            const int before = tl.ntiles;
+            add(1, nstrips - 1 - nright, hf + 1, ny - hf, std::min(ry, ny - 2 * hf));
+            bulk_tiles = tl.ntiles - before;
+        }
+        nblocks = tl.frame_blocks + cdiv(bulk_tiles, 4);
+    } else {
+        if (part == 2 && split) add(1, nstrips - 1 - nright, hf + 1, ny - hf, std::min(ry, ny - 2 * hf));
+        if (tl.ntiles == 0) return hipSuccess;  // part 2 of a field that is all frame
+        nblocks = cdiv(tl.ntiles, 4);
+        fs = FrameSync{};
+    }
+    const dim3 grid(nblocks), block(256);
     const int sw = cfg.xcd_swizzle;
     const int sign = (p.vx >= 0.0 ? 2 : 0) + (p.vy >= 0.0 ? 1 : 0);
 #define CSIM_LAUNCH_O(SXV, SYV)                                                                        \
     hipLaunchKernelGGL((k_sweepO_dpp<DIV, T, SXV, SYV>), grid, block, cfg.lds_bytes, st, in, out, nx, ny, pitch, \
-                       nstrips, tl, sw, p, bc, fin)
+                       nstrips, tl, sw, p, bc, fin, fs)
     if (DIV == 3) {  // coefficient form: the upwind directions are folded into the coefficients
         CSIM_LAUNCH_O(1, 1);
     } else {
@@ -1038,30 +1115,32 @@ static hipError_t sweepO_div(const double* in, double* out, int nx, int ny, int 
 
 template <int T>
 static hipError_t sweepO_T(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
-                           const SweepCfg& cfg, const Bc2& bc, const FinLines& fin, int part, hipStream_t st) {
+                           const SweepCfg& cfg, const Bc2& bc, const FinLines& fin, int part, hipStream_t st,
+                           const FrameSync& fs) {
     switch (p.div_mode) {
-        case 0: return sweepO_div<0, T>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st);
-        case 1: return sweepO_div<1, T>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st);
-        case 3: return sweepO_div<3, T>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st);
-        default: return sweepO_div<2, T>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st);
+        case 0: return sweepO_div<0, T>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st, fs);
+        case 1: return sweepO_div<1, T>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st, fs);
+        case 3: return sweepO_div<3, T>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st, fs);
+        default: return sweepO_div<2, T>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st, fs);
     }
 }
 
 // overlapped-strip multi-step sweep, T = 2..6 (kind[] / part: see internal.hpp)
 hipError_t launch_sweepO(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
                          const SweepCfg& cfg, const int kind[4], double value, int T, int part,
-                         hipStream_t st, double* const fin_lines[4]) {
+                         hipStream_t st, double* const fin_lines[4], const FrameSync* sync) {
     Bc2 bc;
     for (int s = 0; s < 4; ++s) bc.kind[s] = kind[s];
     bc.value = value;
     FinLines fin;
     for (int s = 0; s < 4; ++s) fin.line[s] = fin_lines ? fin_lines[s] : nullptr;
+    const FrameSync fs = sync ? *sync : FrameSync{};
     switch (T) {
-        case 2: return sweepO_T<2>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st);
-        case 3: return sweepO_T<3>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st);
-        case 4: return sweepO_T<4>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st);
-        case 5: return sweepO_T<5>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st);
-        default: return sweepO_T<6>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st);
+        case 2: return sweepO_T<2>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st, fs);
+        case 3: return sweepO_T<3>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st, fs);
+        case 4: return sweepO_T<4>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st, fs);
+        case 5: return sweepO_T<5>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st, fs);
+        default: return sweepO_T<6>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st, fs);
     }
 }
 

@@ -184,7 +184,9 @@ int csim_stepper_sum(csim_stepper* s, double* out);
  *   "xcd_swizzle"    0/1 XCD-aware block->tile map
  *   "overlap"        0 serial exchange, 1 (default) frame tiles first and the exchange under the bulk sweep,
  *                    2 additionally the next frame on its own stream beside the bulk ("bulk_lds": dynamic LDS
- *                    per bulk workgroup as an occupancy cap, 0 = none)
+ *                    per bulk workgroup as an occupancy cap, 0 = none), 3 frame and bulk in ONE launch: the
+ *                    frame wavefronts publish a flag the comm stream waits on (hipStreamWaitValue64), so the
+ *                    exchange starts under the running kernel without an event or a second launch
  *   "external_halo"  0/1 the caller carries the faces (csim_stepper_halo_* / _faces_*)
  *   "profile"        0 off, k >= 1: HIP events around the sweep launch(es) of every k-th pass
  *                    (csim_stepper_kernel_time)

@@ -32,7 +32,9 @@ def test_bench_line_contract_single_gpu():
     assert abs(r["value"] - 1536 * 1024 * 37 / (r["ms_per_step"] * 37 * 1e-3) / 1e6) < 1e-6 * r["value"]
     rf = r["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0 < rf["frac"] <= 1.0
+    assert rf["step_equivalent_x_peak"] == rf["step_equivalent_gbs"] / 8000.0
+    assert r["roofline_valu"]["bound"] == "fp64-valu" and 0 < r["roofline_valu"]["frac"] < 1
     assert r["config"]["relative_mass_drift"] < 1e-9
 
 
@@ -41,7 +43,10 @@ def test_bench_multi_rank_path_on_self_linked_torus():
     cfg = r["config"]
     assert cfg["halo_transport"] == "rccl"
     sched = cfg["exchange_schedules_ms_per_step"]
-    assert sched["chosen"] in sched and len(sched) == 5  # overlap 1, 0 and the two opt-in overlap-2 variants
+    # overlap 3 (merged launch), 1, 0 and the two opt-in overlap-2 variants, + "chosen"
+    assert sched["chosen"] in sched and len(sched) == 6 and any(k.startswith("overlap-3") for k in sched)
+    pr = cfg["per_rank"]
+    assert len(pr) == 1 and pr[0]["rank"] == 0 and pr[0]["kernel_avg_ms"] > 0 and pr[0]["neighbours"] == [0, 0, 0, 0]
     assert cfg["relative_mass_drift"] < 1e-9  # a lost or misplaced face would leak mass at the seams
 
 

@@ -17,21 +17,30 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shape", nargs="+", default=["8192x16384", "8192x8192", "4096x8192"])
     ap.add_argument("--steps", type=int, default=1200)
+    ap.add_argument("--modes", nargs="+", default=["single", "torus-overlap", "torus-merged", "torus-concurrent",
+                                                   "torus-concurrent-nolds", "torus-serial"])
     args = ap.parse_args()
     csim = load_package()
     csim.lib()
     csim.set_device(0)
     for sh in args.shape:
         nx, ny = (int(v) for v in sh.split("x"))
-        for mode in ("single", "torus-overlap", "torus-concurrent", "torus-concurrent-nolds", "torus-serial"):
+        for mode in args.modes:
             d = csim.decomp_init(1, 0, nx, ny)
-            if mode != "single":
+            if not mode.startswith("single"):
                 for k in range(4):
                     d.nbr[k] = 0
             st = csim.Stepper(d, 1.0, 1.0, csim.bc_codes("dddd"))
-            if mode != "single":
+            if mode.startswith("single"):
+                for tok in mode.split("+")[1:]:
+                    k, v = tok.split("=")
+                    st.set_option(k, int(v))
+            else:
                 st.comm_init(csim.comm_unique_id())
-                st.set_option("overlap", {"torus-overlap": 1, "torus-serial": 0}.get(mode, 2))
+                st.set_option("overlap", {"torus-overlap": 1, "torus-serial": 0, "torus-merged": 3}.get(mode.split("+")[0], 2))
+                for tok in mode.split("+")[1:]:   # e.g. torus-merged+frame_fence=1+frame_prio=0
+                    k, v = tok.split("=")
+                    st.set_option(k, int(v))
                 if mode == "torus-concurrent-nolds":
                     st.set_option("bulk_lds", 0)
             st.init_gaussian()
