@@ -155,7 +155,6 @@ struct csim_stepper {
     unsigned long long* frame_flag = nullptr;
     unsigned long long pass_no = 0;
     int frame_fence = 0, frame_prio = 1;  // experiment switches of mode 3, see FrameSync
-    int reserve_cus = 0;                  // CUs masked out of the compute stream (option "reserve_cus")
     // asynchronous snapshot of the interior (device staging copy + pinned host buffer + I/O stream)
     double* snap_d = nullptr;
     double* snap_h = nullptr;
@@ -1309,33 +1308,6 @@ int csim_stepper_set_option(csim_stepper* s, const char* key, long value) {
         if (value == 3 && s->multi && !s->frame_flag)
             return fail(CSIM_ERR_STATE, "overlap 3 needs hipStreamWaitValue64 / signal memory, which this device or runtime refused");
         s->overlap = static_cast<int>(value);
-    } else if (k == "reserve_cus") {
-        // the compute stream is re-created with a CU mask that leaves `value` CUs (spread evenly over the
-        // mask) to everything else — the RCCL kernel and the small pack / unpack / ghost kernels of the comm
-        // stream then find idle CUs instead of sharing SIMDs with the VALU-bound sweep.  0 = whole chip.
-        CSIM_REQUIRE(value >= 0 && value <= 64, "reserve_cus must be 0..64");
-        int dev = 0;
-        CSIM_HIP(hipGetDevice(&dev));
-        hipDeviceProp_t prop;
-        CSIM_HIP(hipGetDeviceProperties(&prop, dev));
-        const int ncu = prop.multiProcessorCount;
-        CSIM_HIP(hipStreamSynchronize(s->s_comp));
-        hipStream_t fresh = nullptr;
-        if (value == 0) {
-            CSIM_HIP(hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking));
-        } else {
-            std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-            for (int cu = 0; cu < ncu; ++cu) mask[cu / 32] |= 1u << (cu % 32);
-            const int nres = static_cast<int>(value);
-            for (int k2 = 0; k2 < nres; ++k2) {
-                const int cu = static_cast<int>((static_cast<long>(k2) * ncu) / nres + ncu / (2 * nres));
-                mask[cu / 32] &= ~(1u << (cu % 32));
-            }
-            CSIM_HIP(hipExtStreamCreateWithCUMask(&fresh, static_cast<uint32_t>(mask.size()), mask.data()));
-        }
-        CSIM_HIP(hipStreamDestroy(s->s_comp));
-        s->s_comp = fresh;
-        s->reserve_cus = static_cast<int>(value);
     } else if (k == "frame_fence") {
         CSIM_REQUIRE(value >= 0 && value <= 2, "frame_fence must be 0..2");
         s->frame_fence = static_cast<int>(value);
@@ -1389,7 +1361,6 @@ int csim_stepper_get_option(const csim_stepper* s, const char* key, long* value)
     else if (k == "external_halo") *value = s->external;
     else if (k == "fuse") *value = s->fuse;
     else if (k == "contract") *value = s->contract;
-    else if (k == "reserve_cus") *value = s->reserve_cus;
     else if (k == "autotune") *value = s->autotune;
     else if (k == "profile") *value = s->profile;
     else return fail(CSIM_ERR_ARG, "unknown option: " + k);
