@@ -177,31 +177,9 @@ int main(int argc, char** argv) {
         if (snap) st.snapshot_begin();
         int k = no_output ? cfg.steps - n : std::min(cfg.out_every - n % cfg.out_every, cfg.steps - n);
 #ifdef CSIM_WITH_MPI
-        if (world_size > 1 && halo_mpi) {  // reference-style MPI faces around single GPU steps
-            k = 1;
-            std::vector<double> sb[4], rb[4];
-            double* sp[4] = {nullptr, nullptr, nullptr, nullptr};
-            const double* rp[4] = {nullptr, nullptr, nullptr, nullptr};
-            const int nb[4] = {dec.nbr_lr[0], dec.nbr_lr[1], dec.nbr_du[0], dec.nbr_du[1]};
-            for (int s = 0; s < 4; ++s)
-                if (nb[s] != MPI_PROC_NULL) {
-                    sb[s].resize(s < 2 ? dec.ny_local : dec.nx_local);
-                    rb[s].resize(sb[s].size());
-                    sp[s] = sb[s].data();
-                    rp[s] = rb[s].data();
-                }
-            climate::check(csim_stepper_halo_pack(st.handle(), sp));
-            MPI_Request rq[8];
-            int nr = 0;
-            const int opp[4] = {1, 0, 3, 2};
-            for (int s = 0; s < 4; ++s)
-                if (nb[s] != MPI_PROC_NULL) {
-                    MPI_Irecv(rb[s].data(), static_cast<int>(rb[s].size()), MPI_DOUBLE, nb[s], 100 + opp[s], MPI_COMM_WORLD, &rq[nr++]);
-                    MPI_Isend(sb[s].data(), static_cast<int>(sb[s].size()), MPI_DOUBLE, nb[s], 100 + s, MPI_COMM_WORLD, &rq[nr++]);
-                }
-            MPI_Waitall(nr, rq, MPI_STATUSES_IGNORE);
-            climate::check(csim_stepper_halo_unpack(st.handle(), rp));
-        }
+        if (world_size > 1 && halo_mpi)  // reference-style MPI faces, once per fused pass (stepper.hpp)
+            st.advance_mpi(MPI_COMM_WORLD, cfg.D, cfg.dt, cfg.vx, cfg.vy, k);
+        else
 #endif
         st.run(cfg.D, cfg.dt, cfg.vx, cfg.vy, k);  // enqueued, not waited for
         if (snap) write_interior_netcdf(ncid, varid, st.snapshot_wait(), dec, time_index++);

@@ -7,8 +7,10 @@
 // only touched by upload()/download() (the snapshot point, reference src/io.cpp:402-424).
 // Errors surface as std::runtime_error carrying csim_last_error().
 #pragma once
+#include <algorithm>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "core.hpp"
 #include "csim.h"
@@ -27,6 +29,7 @@ class Stepper {
   public:
     Stepper(const Decomp2D& dec, const BCConfig& bc, double dx, double dy, double bc_value = 0.0) {
         const csim_decomp d = dec.c_abi();
+        dec_ = d;
         const int codes[4] = {bc_code(bc.left), bc_code(bc.right), bc_code(bc.bottom), bc_code(bc.top)};
         check(csim_stepper_create(&d, dx, dy, codes, bc_value, &h_));
     }
@@ -66,6 +69,76 @@ class Stepper {
     void run(double D, double dt, double vx, double vy, int nsteps) {
         check(csim_stepper_run(h_, D, dt, vx, vy, nsteps));
     }
+#ifdef CSIM_WITH_MPI
+    // `nsteps` reference steps with the faces carried by the caller's MPI (option "external_halo" = 1): what
+    // reference src/halo.cpp:28-46 does every step — Irecv / Isend per neighbour, Waitall — but once per
+    // fused pass: faces of the pass's depth in 8 directions while at least three steps remain, then single
+    // steps with the reference's own 1-cell edge lines, so that the ghost ring left behind is the
+    // reference's.  Every rank derives the same schedule from csim_stepper_fuse_limit.
+    void advance_mpi(MPI_Comm comm, double D, double dt, double vx, double vy, int nsteps) {
+        int depth = 1;
+        check(csim_stepper_fuse_limit(h_, &depth));
+        int remaining = nsteps;
+        std::vector<double> sb[8], rb[8];
+        MPI_Request rq[16];
+        while (remaining >= 3 && depth >= 2) {
+            const int t = std::min(depth, remaining - 1);
+            int peers[8], lens[8];
+            check(csim_stepper_faces_neighbors(h_, t, peers, lens));
+            double* sp[8];
+            const double* rp[8];
+            for (int d = 0; d < 8; ++d) {
+                sb[d].resize(peers[d] >= 0 ? static_cast<size_t>(lens[d]) : 0);
+                rb[d].resize(sb[d].size());
+                sp[d] = peers[d] >= 0 ? sb[d].data() : nullptr;
+                rp[d] = peers[d] >= 0 ? rb[d].data() : nullptr;
+            }
+            check(csim_stepper_faces_pack(h_, t, sp));
+            int nr = 0;
+            for (int d = 0; d < 8; ++d)
+                if (peers[d] >= 0) {  // the face that left the peer in the opposite direction arrives here
+                    const int opp = d < 4 ? (d ^ 1) : 11 - d;
+                    MPI_Irecv(rb[d].data(), lens[d], MPI_DOUBLE, peers[d], 200 + opp, comm, &rq[nr++]);
+                    MPI_Isend(sb[d].data(), lens[d], MPI_DOUBLE, peers[d], 200 + d, comm, &rq[nr++]);
+                }
+            MPI_Waitall(nr, rq, MPI_STATUSES_IGNORE);
+            check(csim_stepper_faces_unpack(h_, t, rp));
+            run(D, dt, vx, vy, t);
+            remaining -= t;
+        }
+        // depth-1 lines: ny doubles left/right, nx bottom/top (src/halo.cpp:12-18 spans), to the four side peers
+        int peers1[4] = {CSIM_NO_NEIGHBOR, CSIM_NO_NEIGHBOR, CSIM_NO_NEIGHBOR, CSIM_NO_NEIGHBOR};
+        {
+            csim_msg sends[8], recvs[8];
+            int ns = 0, nrv = 0;
+            check(csim_exchange_plan(&dec_, 1, sends, &ns, recvs, &nrv));
+            for (int k = 0; k < ns; ++k) peers1[sends[k].dir] = sends[k].peer;
+        }
+        while (remaining > 0) {
+            double* sp[4];
+            const double* rp[4];
+            for (int d = 0; d < 4; ++d) {
+                const size_t n = peers1[d] >= 0 ? static_cast<size_t>(d < 2 ? dec_.ny_local : dec_.nx_local) : 0;
+                sb[d].resize(n);
+                rb[d].resize(n);
+                sp[d] = n ? sb[d].data() : nullptr;
+                rp[d] = n ? rb[d].data() : nullptr;
+            }
+            check(csim_stepper_halo_pack(h_, sp));
+            int nr = 0;
+            for (int d = 0; d < 4; ++d)
+                if (peers1[d] >= 0) {
+                    MPI_Irecv(rb[d].data(), static_cast<int>(rb[d].size()), MPI_DOUBLE, peers1[d], 100 + (d ^ 1), comm, &rq[nr++]);
+                    MPI_Isend(sb[d].data(), static_cast<int>(sb[d].size()), MPI_DOUBLE, peers1[d], 100 + d, comm, &rq[nr++]);
+                }
+            MPI_Waitall(nr, rq, MPI_STATUSES_IGNORE);
+            check(csim_stepper_halo_unpack(h_, rp));
+            run(D, dt, vx, vy, 1);
+            --remaining;
+        }
+    }
+#endif
+
     // one-off chunking trial on this GPU (otherwise done inside the first long run())
     void tune(double D, double dt, double vx, double vy) { check(csim_stepper_tune(h_, D, dt, vx, vy)); }
     void sync() { check(csim_stepper_sync(h_)); }
@@ -85,6 +158,7 @@ class Stepper {
 
   private:
     csim_stepper* h_ = nullptr;
+    csim_decomp dec_{};
 };
 
 }  // namespace climate

@@ -439,6 +439,40 @@ def test_full_field_16384_exactly_what_bench_times(csim, bc, ic):
     st.close()
 
 
+def _full_field(csim, nx, ny, D, vx, vy, bc, runs, seed, tiles=16):
+    """whole field incl. the ghost ring vs `tiles` oracle tiles on as many threads, after each run of `runs`"""
+    u0 = np.zeros((ny + 2, nx + 2))
+    u0[1:-1, 1:-1] = np.random.default_rng(seed).random((ny, nx))
+    w = ora.World(tiles, nx, ny)
+    w.scatter(np.ascontiguousarray(u0[1:-1, 1:-1]))
+    st = csim.Stepper.single(nx, ny, 1.0, 1.0, csim.bc_codes(bc))
+    st.upload(u0)
+    del u0
+    for steps in runs:
+        st.run(D, 0.1, vx, vy, steps)
+        got = st.download()
+        w.run(D, vx, vy, 0.1, ora.bc_codes(bc), steps, threads=tiles)
+        want = w.gather_full()
+        assert np.array_equal(got, want), (nx, ny, bc, steps, float(np.abs(got - want).max()))
+        del got, want
+    st.close()
+
+
+def test_full_field_config2_4096_and_config3_8192(csim):
+    """BASELINE configs[1] (4096^2 diffusion-only, periodic) and configs[2] (8192^2, Dirichlet, both upwind
+    branches): every cell and ghost after a tuned-chunk run (30 steps = 5 x T=6) plus a 7-step tail (4 + 3)"""
+    _full_field(csim, 4096, 4096, 1.0, 0.0, 0.0, "pppp", [30, 7], 201)
+    _full_field(csim, 8192, 8192, 0.05, 0.5, 0.25, "dddd", [30, 7], 202)
+    _full_field(csim, 8192, 8192, 0.05, -0.5, -0.25, "dddd", [12], 203)
+
+
+def test_full_field_config5_32768_neumann(csim):
+    """BASELINE configs[4]'s grid, 32768 x 32768 all-Neumann (2 x 8.6 GB on the device), as ONE field: the
+    reference is decomposition-invariant, so this is also what the 4 x 2 run must assemble to.  Every cell
+    and ghost after 30 steps (chunk-height trial + five T=6 passes) vs 16 oracle tiles."""
+    _full_field(csim, 32768, 32768, 0.05, 0.5, 0.25, "nnnn", [30], 204)
+
+
 def test_full_size_config5_32768_neumann(csim):
     """BASELINE configs[4]: 32768 x 32768, all-Neumann (2 x 8.6 GB on the device).  The reference is
     decomposition-invariant, so the single-GPU field is what the 4 x 2 run must give as well."""
