@@ -234,7 +234,7 @@ def main():
                     help="N > 1: -1 pick the fastest exchange schedule on this node, 0/1/2 force one")
     ap.add_argument("--lds-bytes", type=int, default=0, help="occupancy limiter experiment (see csim.h)")
     ap.add_argument("--fuse", type=int, default=-1,
-                    help="time steps per HBM pass: -1 auto (deepest available), 0 off, 2..6")
+                    help="time steps per HBM pass: -1 auto (cheapest split of the run into passes of 2..7 steps), 0 off, 2..7")
     args = ap.parse_args()
     assert len(args.bc) == 4 and set(args.bc) <= set("dnp"), "--bc takes four of d/n/p"
 
@@ -412,7 +412,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     # dominant kernel = the one that advanced most of the timed steps
-    kinds = {t: st.kernel_time(t) for t in (1, 2, 3, 4, 5, 6)}
+    kinds = {t: st.kernel_time(t) for t in (1, 2, 3, 4, 5, 6, 7)}
     steps_per_launch = max(kinds, key=lambda t: t * kinds[t][1])
     kern_ms, launches = kinds[steps_per_launch]
     comm_ms, comm_n = st.comm_time()

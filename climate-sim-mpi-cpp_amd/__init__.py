@@ -437,7 +437,7 @@ class Stepper:
             return ms.value, n.value
         if steps_per_launch is not None:
             return one(steps_per_launch)
-        parts = [(t,) + one(t) for t in (1, 2, 3, 4, 5, 6)]
+        parts = [(t,) + one(t) for t in (1, 2, 3, 4, 5, 6, 7)]
         return (sum(p[1] for p in parts), sum(p[2] for p in parts), sum(p[0] * p[2] for p in parts))
 
     def comm_time(self):

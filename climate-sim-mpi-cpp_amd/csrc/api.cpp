@@ -175,7 +175,7 @@ struct csim_stepper {
                                // for the next fused pass (ev_recv2 marks the end of that)
     int bulk_lds = 41984;      // mode 2: dynamic LDS per bulk workgroup = 3 instead of 4 workgroups per CU, so
                                // that frame and RCCL workgroups always find a free slot
-    int fuse = -1;  // time steps per HBM pass: -1 auto (deepest available), 0/1 off, 2..6 depth
+    int fuse = -1;  // time steps per HBM pass: -1 auto (cheapest split, see plan_passes), 0/1 off, 2..7 depth
     int contract = 0;  // 1: opt-in contracted arithmetic (5-point FMA stencil), NOT bit-identical to the reference
     int external = 0;  // halos are carried by the caller (csim_stepper_halo_pack/_unpack), not RCCL
     int profile = 0;        // 0 off, k >= 1: HIP events around every k-th pass
@@ -298,7 +298,7 @@ static size_t face_doubles(int d, int H, int nx, int ny) {
 int csim_exchange_plan(const csim_decomp* dec, int depth, csim_msg sends[8], int* nsend, csim_msg recvs[8],
                        int* nrecv) {
     CSIM_REQUIRE(dec && sends && nsend && recvs && nrecv, "null argument");
-    CSIM_REQUIRE(depth >= 1 && depth <= MAX_FUSE, "depth must be 1..6");
+    CSIM_REQUIRE(depth >= 1 && depth <= MAX_FUSE, "depth must be 1..7");
     static const int recv_order1[4] = {CSIM_RIGHT, CSIM_LEFT, CSIM_TOP, CSIM_BOTTOM};
     static const int recv_order8[8] = {1, 0, 3, 2, 7, 6, 5, 4};
     int nbr8[8];
@@ -819,7 +819,7 @@ int csim_stepper_fuse_limit(const csim_stepper* s, int* depth) {
 
 int csim_stepper_faces_neighbors(const csim_stepper* s, int depth, int peers[8], int lengths[8]) {
     CSIM_REQUIRE(s && peers && lengths, "null argument");
-    CSIM_REQUIRE(depth_ok(s, depth), "face depth must be 2..6 and fit the tile");
+    CSIM_REQUIRE(depth_ok(s, depth), "face depth must be 2..7 and fit the tile");
     for (int d = 0; d < 8; ++d) {
         peers[d] = s->nbr8[d];
         lengths[d] = s->nbr8[d] >= 0 ? static_cast<int>(s->face_len(d, depth)) : 0;
@@ -829,7 +829,7 @@ int csim_stepper_faces_neighbors(const csim_stepper* s, int depth, int peers[8],
 
 int csim_stepper_faces_pack(csim_stepper* s, int depth, double* const host_send[8]) {
     CSIM_REQUIRE(s && host_send, "null argument");
-    CSIM_REQUIRE(depth_ok(s, depth), "face depth must be 2..6 and fit the tile");
+    CSIM_REQUIRE(depth_ok(s, depth), "face depth must be 2..7 and fit the tile");
     if (!s->multi) return CSIM_OK;
     CSIM_HIP(launch_halo2_pack(s->cur, s->nx, s->ny, s->pitch, depth, s->send2, s->s_comp));
     for (int d = 0; d < 8; ++d) {
@@ -844,7 +844,7 @@ int csim_stepper_faces_pack(csim_stepper* s, int depth, double* const host_send[
 
 int csim_stepper_faces_unpack(csim_stepper* s, int depth, const double* const host_recv[8]) {
     CSIM_REQUIRE(s && host_recv, "null argument");
-    CSIM_REQUIRE(depth_ok(s, depth), "face depth must be 2..6 and fit the tile");
+    CSIM_REQUIRE(depth_ok(s, depth), "face depth must be 2..7 and fit the tile");
     if (!s->multi) return CSIM_OK;
     for (int d = 0; d < 8; ++d) {
         if (s->nbr8[d] < 0) continue;
@@ -1200,11 +1200,62 @@ static int tune_rows(csim_stepper* s, const Phys& p, int T) {
     return CSIM_OK;
 }
 
-// deepest fused pass of this stepper with the current options (1 = single steps only)
+// depth of the fused passes of this stepper with the current options (1 = single steps only): what
+// the option "fuse" asks for, or PREF_FUSE — the depth with the lowest cost per step — in auto mode
 static int fused_depth(const csim_stepper* s) {
-    const int depth = std::min(s->fuse < 0 ? MAX_FUSE : s->fuse, s->fuse_cap);
+    const int depth = std::min(s->fuse < 0 ? PREF_FUSE : s->fuse, s->fuse_cap);
     const bool dpp_family = s->cfg.variant == VAR_AUTO || s->cfg.variant == VAR_DPP;
     return depth >= 2 && dpp_family ? depth : 1;
+}
+
+// Pass depths of a run of K steps.  "fuse" = N: as few passes as possible of balanced depth <= N.  Auto:
+// the cheapest split by a small dynamic programme over the measured cost of one time step inside a pass
+// of depth T relative to T = 6 (16384^2, DESIGN.md §7: shallow passes are HBM-bound and cost almost as much
+// as a deep one: T = 5 costs 9 % more per step than T = 6; T = 7 pays 12.5 % instead of 9.4 % overlap columns
+// but moves fewer bytes per step and measures 0.4 % above T = 6, so it is used where it saves a whole pass:
+// 20 steps = 7 + 7 + 6 instead of 4 x 5, +11 %) plus a small fixed cost per pass.  A run of
+// two or more steps never contains a single-step pass unless it must (tiles only two cells deep and an odd
+// K): one step alone costs 4.5 steps of a deep pass, so the programme avoids it by itself.  The result
+// depends on (K, cap) only, so every rank of a decomposition derives the same schedule.
+static const double STEP_COST[MAX_FUSE + 1] = {0.0, 4.52, 2.32, 1.55, 1.206, 1.09, 1.0, 1.005};
+static const double PASS_COST = 0.05;
+static void plan_passes(int K, int cap, bool balanced, std::vector<int>& out) {
+    out.clear();
+    if (K <= 0) return;
+    if (cap < 2) {
+        out.assign(static_cast<size_t>(K), 1);
+        return;
+    }
+    if (balanced) {
+        int remaining = K;
+        while (remaining > 0) {
+            const int npass = (remaining + cap - 1) / cap;
+            const int t = remaining < 2 ? 1 : (remaining + npass - 1) / npass;
+            out.push_back(t);
+            remaining -= t;
+        }
+        return;
+    }
+    const int pref = std::min(cap, PREF_FUSE);
+    int lead = 0;  // long runs: passes of the preferred depth, the last <= 8 * pref steps are planned
+    if (K > 8 * pref) lead = (K - 8 * pref + pref - 1) / pref;
+    out.assign(static_cast<size_t>(lead), pref);
+    const int R = K - lead * pref;
+    std::vector<double> best(static_cast<size_t>(R) + 1, 1e300);
+    std::vector<int> pick(static_cast<size_t>(R) + 1, 0);
+    best[0] = 0.0;
+    for (int k = 1; k <= R; ++k)
+        for (int t = 1; t <= std::min(cap, k); ++t) {
+            const double c = best[static_cast<size_t>(k - t)] + t * STEP_COST[t] + PASS_COST;
+            if (c < best[static_cast<size_t>(k)]) {
+                best[static_cast<size_t>(k)] = c;
+                pick[static_cast<size_t>(k)] = t;
+            }
+        }
+    std::vector<int> tail;
+    for (int k = R; k > 0; k -= pick[static_cast<size_t>(k)]) tail.push_back(pick[static_cast<size_t>(k)]);
+    std::sort(tail.begin(), tail.end(), [](int a, int b) { return a > b; });  // deep passes first
+    out.insert(out.end(), tail.begin(), tail.end());
 }
 
 // the one-off trial of csim_stepper_run's first long call, on request (e.g. before a timed loop)
@@ -1222,11 +1273,13 @@ int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy,
     // the face depth).
     const int depth = fused_depth(s);
     const bool can_fuse = depth >= 2;
+    const bool auto_depth = s->fuse < 0;
+    const int cap = !can_fuse ? 1 : auto_depth ? std::min(MAX_FUSE, s->fuse_cap) : depth;
     if (s->multi && s->external) {
         // the caller carries the faces: one step (depth-1 faces) or one fused pass per call
         if (nsteps == 1 && !s->halo_fresh)
             return fail(CSIM_ERR_STATE, "external halo transport: csim_stepper_halo_unpack first");
-        if (nsteps >= 2 && !(can_fuse && nsteps <= depth))
+        if (nsteps >= 2 && !(can_fuse && nsteps <= cap))
             return fail(CSIM_ERR_STATE, "external halo transport: a call advances 1 step or one fused pass");
     } else if (s->multi && !s->comm) {
         return fail(CSIM_ERR_STATE, "multi-rank stepper needs csim_stepper_comm_init before run");
@@ -1242,26 +1295,19 @@ int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy,
         int rc = tune_rows(s, p, depth);
         if (rc) return rc;
     }
-    auto pass_len = [&](int remaining) {
-        if (!can_fuse || remaining < 2) return 1;
-        // as few passes as possible, of balanced depth (20 steps = 4 x 5 rather than 6 + 6 + 6 + 2:
-        // a shallow pass costs almost as much as a deep one)
-        const int npass = (remaining + depth - 1) / depth;
-        return (remaining + npass - 1) / npass;
-    };
-    int remaining = nsteps;
-    while (remaining > 0) {
-        const int t = pass_len(remaining);
+    std::vector<int> plan;
+    plan_passes(nsteps, cap, !auto_depth, plan);
+    for (size_t k = 0; k < plan.size(); ++k) {
+        const int t = plan[k];
         int rc;
         if (t >= 2) {
-            const int nt = pass_len(remaining - t);
-            const bool last = remaining == t;
-            rc = pass_fused(s, p, t, (!last && nt >= 2) ? nt : 0, last);
+            const bool last = k + 1 == plan.size();
+            const int nt = last ? 0 : plan[k + 1];
+            rc = pass_fused(s, p, t, nt >= 2 ? nt : 0, last);
         } else {
             rc = pass_single(s, p, g);
         }
         if (rc) return rc;
-        remaining -= t;
     }
     return join_frame(s);
 }
@@ -1327,7 +1373,7 @@ int csim_stepper_set_option(csim_stepper* s, const char* key, long value) {
         }
         s->contract = static_cast<int>(value);
     } else if (k == "fuse") {
-        CSIM_REQUIRE(value >= -1 && value <= MAX_FUSE, "fuse must be -1 (auto) or 0..6");
+        CSIM_REQUIRE(value >= -1 && value <= MAX_FUSE, "fuse must be -1 (auto) or 0..7");
         s->fuse = static_cast<int>(value);
     } else if (k == "lds_bytes") {
         CSIM_REQUIRE(value >= 0 && value <= 65536, "lds_bytes must be 0..65536");
@@ -1370,7 +1416,7 @@ int csim_stepper_get_option(const csim_stepper* s, const char* key, long* value)
 int csim_stepper_kernel_time(csim_stepper* s, int steps_per_launch, double* total_ms,
                              long* launches) {
     CSIM_REQUIRE(s && total_ms && launches, "null argument");
-    CSIM_REQUIRE(steps_per_launch >= 1 && steps_per_launch <= MAX_FUSE, "steps_per_launch must be 1..6");
+    CSIM_REQUIRE(steps_per_launch >= 1 && steps_per_launch <= MAX_FUSE, "steps_per_launch must be 1..7");
     int rc = prof_fold(s);
     if (rc) return rc;
     *total_ms = s->prof_ms[steps_per_launch];

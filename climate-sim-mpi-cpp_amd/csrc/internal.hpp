@@ -74,7 +74,7 @@ struct SweepCfg {
 // All pointers are device pointers in the padded layout above.
 hipError_t launch_sweep(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
                         const SweepCfg& cfg, hipStream_t st);
-// T = 2..6 fused time steps per pass (overlapped strips).  kind[s] = CSIM_BC_* on physical sides, 3 on
+// T = 2..7 fused time steps per pass (overlapped strips).  kind[s] = CSIM_BC_* on physical sides, 3 on
 // neighbour sides; part: 0 = every tile, 1 = frame tiles only, 2 = all but the frame tiles.
 // fin_lines (last pass of a run, all four or nullptr): per side the level T-1 line the final ghost
 // fill needs — see FinLines in kernels.hip
@@ -93,8 +93,9 @@ struct FrameSync {
 hipError_t launch_sweepO(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
                          const SweepCfg& cfg, const int kind[4], double value, int T, int part,
                          hipStream_t st, double* const fin_lines[4] = nullptr, const FrameSync* sync = nullptr);
-constexpr int MAX_FUSE = 6;       // deepest temporal blocking
-constexpr int GHOST_EXTRA = 5;    // device-only ghost layers beyond the reference's one (= MAX_FUSE-1)
+constexpr int MAX_FUSE = 7;       // deepest temporal blocking (123 VGPRs: still 4 waves/SIMD; 8 would drop to 3)
+constexpr int PREF_FUSE = 6;      // depth with the lowest measured cost per time step (7 pays more overlap columns)
+constexpr int GHOST_EXTRA = 6;    // device-only ghost layers beyond the reference's one (= MAX_FUSE-1)
 // faces of depth H = 2..6 (8 directions: L R B T BL BR TL TR; nullptr = no neighbour there);
 // sizes H*(ny+2) (L,R), H*(nx+2) (B,T), H*H (corners)
 hipError_t launch_halo2_pack(const double* f, int nx, int ny, int pitch, int depth,

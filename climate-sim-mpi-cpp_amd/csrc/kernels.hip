@@ -6,8 +6,8 @@
 //     written once per PASS: vertical reuse in registers while a wavefront marches up its column
 //     strip, horizontal reuse through cross-lane DPP moves (an LDS-staged variant is kept for
 //     comparison), row loads kept in flight to cover HBM latency, XCD-aware block->tile map;
-//   * temporal blocking: up to six time levels stay in registers per pass (k_sweepO_dpp, the
-//     default), which divides the HBM traffic per step by six and leaves the kernel bound by the
+//   * temporal blocking: up to seven time levels stay in registers per pass (k_sweepO_dpp, the
+//     default), which divides the HBM traffic per step by as much and leaves the kernel bound by the
 //     reference's own fp64 add/mul stream.
 // Kernels, in file order: k_sweep_dpp (1 step/pass), k_sweepO_dpp (2-6 steps/pass, overlapped
 // strips, DEFAULT), k_sweep_lds (the LDS-staged design, measured alternative), k_sweep_naive
@@ -1125,7 +1125,7 @@ static hipError_t sweepO_T(const double* in, double* out, int nx, int ny, int pi
     }
 }
 
-// overlapped-strip multi-step sweep, T = 2..6 (kind[] / part: see internal.hpp)
+// overlapped-strip multi-step sweep, T = 2..7 (kind[] / part: see internal.hpp)
 hipError_t launch_sweepO(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
                          const SweepCfg& cfg, const int kind[4], double value, int T, int part,
                          hipStream_t st, double* const fin_lines[4], const FrameSync* sync) {
@@ -1140,7 +1140,8 @@ hipError_t launch_sweepO(const double* in, double* out, int nx, int ny, int pitc
         case 3: return sweepO_T<3>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st, fs);
         case 4: return sweepO_T<4>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st, fs);
         case 5: return sweepO_T<5>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st, fs);
-        default: return sweepO_T<6>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st, fs);
+        case 6: return sweepO_T<6>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st, fs);
+        default: return sweepO_T<7>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st, fs);
     }
 }
 

@@ -78,7 +78,7 @@ int csim_decomp_init(int size, int rank, int nx_global, int ny_global, csim_deco
 /* The halo exchange of one rank as an ordered message list (pure host arithmetic, no GPU): what
  * the stepper posts inside ONE ncclGroupStart/End — replaces the <= 8 MPI_Isend/Irecv + MPI_Waitall of
  * reference src/halo.cpp:28-46.  depth 1: the four edge lines (ny / nx doubles, interior span);
- * depth 2..6 (fused passes): faces of that depth in 8 directions 0..7 = left, right, bottom, top,
+ * depth 2..7 (fused passes): faces of that depth in 8 directions 0..7 = left, right, bottom, top,
  * bottom-left, bottom-right, top-left, top-right (depth*(ny+2), depth*(nx+2), depth*depth doubles).
  * sends[k].dir = the direction the face leaves in; recvs[k].dir = the direction it arrives FROM.  RCCL
  * matches the messages of a pair of ranks in posting order, so for every pair (a, b) the k-th send
@@ -148,7 +148,7 @@ int csim_stepper_init_gaussian(csim_stepper* s, double A, double sigma_frac, dou
  * next csim_stepper_run(.., 1).  One step per run call in this mode. */
 int csim_stepper_halo_pack(csim_stepper* s, double* const host_send[4]);
 int csim_stepper_halo_unpack(csim_stepper* s, const double* const host_recv[4]);
-/* deep-face flavour for csim_stepper_run(.., depth) (ONE fused pass of depth = 2..6 steps) in
+/* deep-face flavour for csim_stepper_run(.., depth) (ONE fused pass of depth = 2..7 steps) in
  * external mode: directions 0..7 = left, right, bottom, top, bottom-left, bottom-right, top-left,
  * top-right; _neighbors gives the peer rank (or CSIM_NO_NEIGHBOR) and the face length in doubles
  * per direction (depth*(ny+2), depth*(nx+2), depth*depth).  The face packed for direction d must be
@@ -178,7 +178,8 @@ int csim_stepper_sum(csim_stepper* s, double* out);
  *                    stencil a0 c + aW W + aE E + aS S + aN N in FMA form (5 instead of 15 fp64
  *                    operations per cell); rounding differs by a few ulp per step, L_inf vs the reference
  *                    stays far below the 1e-10 tolerance (tests/test_gpu_contract.py).
- *   "fuse"           time steps per HBM pass: -1 auto (deepest the decomposition allows), 0/1 off, 2..6
+ *   "fuse"           time steps per HBM pass: -1 auto (the cheapest split of a run into passes of 2..7 steps, e.g.
+ *                    1000 = 166 x 6 + 4, 20 = 7 + 7 + 6), 0/1 off, 2..7 balanced passes of at most that depth
  *   "variant"        single-step kernel family: 0 auto, 1 dpp, 2 lds, 3 naive
  *   "rows_per_chunk" rows one wavefront marches per launch (0 auto), "prefetch" (single-step kernel)
  *   "xcd_swizzle"    0/1 XCD-aware block->tile map
@@ -198,7 +199,7 @@ int csim_stepper_set_option(csim_stepper* s, const char* key, long value);
 int csim_stepper_get_option(const csim_stepper* s, const char* key, long* value);
 /* with option "profile"=1: HIP-event time (on the compute stream) and count of the sweep
  * launches since the last reset, per kernel kind: steps_per_launch = 1 selects the single-step
- * kernel, 2..6 the kernels that advance that many time steps per HBM pass */
+ * kernel, 2..7 the kernels that advance that many time steps per HBM pass */
 int csim_stepper_kernel_time(csim_stepper* s, int steps_per_launch, double* total_ms,
                              long* launches);
 /* same sampling, multi-rank runs over RCCL with "overlap" = 1: HIP-event time of the comm-stream chain

@@ -8,7 +8,7 @@ src/halo.cpp:28-43.  Two engines step the local tile:
   --engine oracle        CPU: oracle/cpu_stepper.c (tests the N>1 host logic without a GPU)
   --engine hip-external  GPU: the HIP stepper with csim_stepper_halo_pack/_unpack
                          (several ranks may share one GPU; RCCL refuses that, gloo does not)
-  --engine hip-external{2,3,4}  GPU: same, but 2/3/4 steps per call (one fused pass) with faces
+  --engine hip-external{2..7}  GPU: same, but 2..7 steps per call (one fused pass) with faces
                          of that depth in 8 directions (csim_stepper_faces_pack/_unpack)
 Rank 0 gathers the global interior and compares it bit-for-bit with the golden fixture."""
 import argparse
@@ -81,13 +81,14 @@ def main():
             st.run(m["D"], dt, m["vx"], m["vy"], 1)
         local = st.download()
         st.close()
-    elif args.engine.startswith("hip-external") and args.engine[-1] in "23456":
+    elif args.engine.startswith("hip-external") and args.engine[-1] in "234567":
         # `depth` reference steps per call (one fused HBM pass) with deep faces, then single steps
         depth = int(args.engine[-1])
         csim.lib()
         csim.set_device(0)
         st = csim.Stepper(dec, m["dx"], m["dy"], bc)
         st.set_option("external_halo", 1)
+        st.set_option("fuse", depth)         # (auto mode offers 6, the depth that is cheapest per step)
         st.upload(u)
         depth = min(depth, st.fuse_limit())  # tiny tiles cap the depth (same value on every rank)
         remaining = m["steps"]

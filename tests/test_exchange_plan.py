@@ -6,7 +6,7 @@ post_exchange2 walk exactly that plan.  RCCL matches the messages of a pair of r
 so the first real 2/4/8-GPU run deadlocks or scrambles faces unless, for EVERY ordered pair (a, b):
 the k-th send a posts to b has the length of — and the direction opposite to — the k-th receive b
 posts for a, and nobody waits for a message that is never sent.  Checked here for the process grids
-MPI_Dims_create yields for 2, 4, 6, 8, 3 and 12 ranks, every depth 1..6, with and without remainder
+MPI_Dims_create yields for 2, 4, 6, 8, 3 and 12 ranks, every depth 1..7, with and without remainder
 tiles (reference decomposition: src/decomp.cpp:24-33; reference exchange: src/halo.cpp:28-46)."""
 import collections
 
@@ -25,7 +25,7 @@ def plans(world, nx, ny, depth):
     return decs, [csim.exchange_plan(d, depth) for d in decs]
 
 
-@pytest.mark.parametrize("depth", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("depth", [1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("world,dims", [(2, (2, 1)), (4, (2, 2)), (6, (3, 2)), (8, (4, 2)), (3, (3, 1)), (12, (4, 3))])
 @pytest.mark.parametrize("grid", [(16384, 16384), (1000, 777), (515, 67), (97, 61)])
 def test_every_pair_matches_in_posting_order(world, dims, grid, depth):
@@ -52,7 +52,7 @@ def test_every_pair_matches_in_posting_order(world, dims, grid, depth):
             assert dr == OPPOSITE[ds], (pair, msgs, want)       # it arrives from the opposite direction
 
 
-@pytest.mark.parametrize("depth", [1, 3, 6])
+@pytest.mark.parametrize("depth", [1, 3, 6, 7])
 @pytest.mark.parametrize("world", [2, 4, 6, 8])
 def test_peers_are_the_geometric_neighbours_and_lengths_fit_the_tiles(world, depth):
     nx, ny = 1030, 517      # remainders on the last column / row of tiles
@@ -81,7 +81,7 @@ def test_self_linked_torus_plan_is_consistent_too():
     d = csim.decomp_init(1, 0, 4096, 8192)
     for k in range(4):
         d.nbr[k] = 0
-    for depth in range(1, 7):
+    for depth in range(1, 8):
         sends, recvs = csim.exchange_plan(d, depth)
         assert len(sends) == len(recvs) == (4 if depth == 1 else 8)
         for (ps, ds, ns), (pr, dr, nr) in zip(sends, recvs):   # same peer for all: pure posting order
@@ -93,4 +93,4 @@ def test_plan_rejects_bad_arguments():
     with pytest.raises(csim.CsimError):
         csim.exchange_plan(d, 0)
     with pytest.raises(csim.CsimError):
-        csim.exchange_plan(d, 7)
+        csim.exchange_plan(d, 8)

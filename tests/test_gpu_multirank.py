@@ -18,13 +18,13 @@ def test_hip_stepper_multirank_one_gpu(world):
         assert rc == 0 and "ok=True" in out, (os.path.basename(case), out[-3000:])
 
 
-@pytest.mark.parametrize("depth", [2, 3, 4, 5, 6])
+@pytest.mark.parametrize("depth", [2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("world", [2, 3, 4])
 def test_hip_stepper_fused_passes_multirank_one_gpu(world, depth):
-    """2..6 steps per pass across ranks: deep faces incl. the diagonal corner blocks"""
-    # depth 6 on EVERY golden case of this world size (odd widths, tiny tiles, all BC mixes, the
+    """2..7 steps per pass across ranks: deep faces incl. the diagonal corner blocks"""
+    # depths 6 and 7 on EVERY golden case of this world size (odd widths, tiny tiles, all BC mixes, the
     # three division modes); the other depths on the wide cases
-    cases = cases_with(world) if depth == 6 else [c for c in cases_with(world) if "run_fused" in c]
+    cases = cases_with(world) if depth in (6, 7) else [c for c in cases_with(world) if "run_fused" in c]
     assert cases
     for case in cases:
         rc, out = launch(world, f"hip-external{depth}", case, timeout=600)

@@ -2,8 +2,8 @@
 """tools/pmc_workload.py — the sweep launches whose hardware counters tools/gpu_pmc.sh collects.
 
 A fixed, printed sequence of launches on the bench grid: for each boundary mix, every kernel
-instantiation bench.py can time (single-step k_sweep_dpp, k_sweepO_dpp<T = 2..6>) at the chunk heights
-the on-device trial picks from (T = 5, 6).  The sequence goes to stdout as one JSON line ("PMC_SEQUENCE")
+instantiation bench.py can time (single-step k_sweep_dpp, k_sweepO_dpp<T = 2..7>) at the chunk heights
+the on-device trial picks from (T = 5, 6, 7).  The sequence goes to stdout as one JSON line ("PMC_SEQUENCE")
 so that the post-processor can attribute the k-th sweep dispatch of the profile to its configuration.
 Runs under `rocprofv3 --pmc ...` (one counter set per process run)."""
 import argparse
@@ -33,7 +33,7 @@ def main():
         st = csim.Stepper.single(args.nx, args.ny, 1.0, 1.0, csim.bc_codes(bc))
         st.set_option("autotune", 0)
         st.init_gaussian(1.0, 0.05, 0.5, 0.5)
-        cfgs = [(1, 0), (2, 0), (3, 0), (4, 0)] + [(5, r) for r in args.rows] + [(6, r) for r in args.rows]
+        cfgs = [(1, 0), (2, 0), (3, 0), (4, 0)] + [(T, r) for T in (5, 6, 7) for r in args.rows]
         for T, ry in cfgs:
             st.set_option("fuse", 0 if T == 1 else T)
             st.set_option("rows_per_chunk", ry)
