@@ -8,7 +8,7 @@
 //
 //     | 15 unused | ghost i=0 | interior i=1..nx (128-B aligned) | ghost i=nx+1 | pad ... |
 //
-// `view` points GHOST_EXTRA rows into the allocation: rows -5..-1 and ny+2..ny+6 (and the pad
+// `view` points GHOST_EXTRA rows into the allocation: rows -6..-1 and ny+2..ny+7 (and the pad
 // columns left of i = 0 / right of i = nx+1) exist as device-only ghost layers, which the
 // multi-step-per-pass sweeps read (as halo data on neighbour sides, as don't-care otherwise).
 //
