@@ -1219,15 +1219,31 @@ static int fused_depth(const csim_stepper* s) {
 // depends on (K, cap) only, so every rank of a decomposition derives the same schedule.
 static const double STEP_COST[MAX_FUSE + 1] = {0.0, 4.52, 2.32, 1.55, 1.206, 1.09, 1.0, 1.005};
 static const double PASS_COST = 0.05;
-static void plan_passes(int K, int cap, bool balanced, std::vector<int>& out) {
-    out.clear();
+// The plan is `lead` passes of depth `lead_depth` followed by the passes listed in `tail` (a run of 10^9
+// steps must not materialise 10^8 entries).
+struct PassPlan {
+    long lead = 0;
+    int lead_depth = 1;
+    std::vector<int> tail;
+    long size() const { return lead + static_cast<long>(tail.size()); }
+    int at(long k) const { return k < lead ? lead_depth : tail[static_cast<size_t>(k - lead)]; }
+};
+static void plan_passes(int K, int cap, bool balanced, PassPlan& plan) {
+    plan = PassPlan{};
+    std::vector<int>& out = plan.tail;
     if (K <= 0) return;
     if (cap < 2) {
-        out.assign(static_cast<size_t>(K), 1);
+        plan.lead = K;
+        plan.lead_depth = 1;
         return;
     }
     if (balanced) {
-        int remaining = K;
+        // as few passes as possible, of balanced depth: all but the last few are of depth `cap`
+        if (K > 4 * cap) {
+            plan.lead = (K - 4 * cap) / cap;
+            plan.lead_depth = cap;
+        }
+        int remaining = K - static_cast<int>(plan.lead) * cap;
         while (remaining > 0) {
             const int npass = (remaining + cap - 1) / cap;
             const int t = remaining < 2 ? 1 : (remaining + npass - 1) / npass;
@@ -1237,15 +1253,16 @@ static void plan_passes(int K, int cap, bool balanced, std::vector<int>& out) {
         return;
     }
     const int pref = std::min(cap, PREF_FUSE);
-    int lead = 0;  // long runs: passes of the preferred depth, the last <= 8 * pref steps are planned
-    if (K > 8 * pref) lead = (K - 8 * pref + pref - 1) / pref;
-    out.assign(static_cast<size_t>(lead), pref);
-    const int R = K - lead * pref;
+    // long runs: passes of the preferred depth, the last <= 8 * pref steps are planned
+    if (K > 8 * pref) plan.lead = (K - 8 * pref + pref - 1) / pref;
+    plan.lead_depth = pref;
+    const int R = K - static_cast<int>(plan.lead) * pref;
     std::vector<double> best(static_cast<size_t>(R) + 1, 1e300);
     std::vector<int> pick(static_cast<size_t>(R) + 1, 0);
     best[0] = 0.0;
     for (int k = 1; k <= R; ++k)
         for (int t = 1; t <= std::min(cap, k); ++t) {
+            if (t == 1 && cap >= 3 && K >= 2) continue;  // every k >= 2 splits into 2s and 3s: no single-step pass
             const double c = best[static_cast<size_t>(k - t)] + t * STEP_COST[t] + PASS_COST;
             if (c < best[static_cast<size_t>(k)]) {
                 best[static_cast<size_t>(k)] = c;
@@ -1256,6 +1273,22 @@ static void plan_passes(int K, int cap, bool balanced, std::vector<int>& out) {
     for (int k = R; k > 0; k -= pick[static_cast<size_t>(k)]) tail.push_back(pick[static_cast<size_t>(k)]);
     std::sort(tail.begin(), tail.end(), [](int a, int b) { return a > b; });  // deep passes first
     out.insert(out.end(), tail.begin(), tail.end());
+}
+
+// the pass schedule as pure host arithmetic (no GPU): what csim_stepper_run(nsteps) will launch on a
+// decomposition whose smallest tile is `smallest_tile` cells deep, with option "fuse" = `fuse`
+int csim_pass_schedule(int nsteps, int smallest_tile, int fuse, int* depths, int max_depths, long* npasses) {
+    CSIM_REQUIRE(npasses && nsteps >= 0 && smallest_tile >= 1, "bad argument");
+    CSIM_REQUIRE(fuse >= -1 && fuse <= MAX_FUSE, "fuse must be -1 (auto) or 0..7");
+    CSIM_REQUIRE(max_depths == 0 || depths, "depths is null");
+    const int fuse_cap = std::max(1, std::min(MAX_FUSE, smallest_tile));
+    const int depth = std::min(fuse < 0 ? PREF_FUSE : fuse, fuse_cap);
+    const int cap = depth < 2 ? 1 : fuse < 0 ? std::min(MAX_FUSE, fuse_cap) : depth;
+    PassPlan plan;
+    plan_passes(nsteps, cap, fuse >= 0, plan);
+    *npasses = plan.size();
+    for (long k = 0; k < plan.size() && k < max_depths; ++k) depths[k] = plan.at(k);
+    return CSIM_OK;
 }
 
 // the one-off trial of csim_stepper_run's first long call, on request (e.g. before a timed loop)
@@ -1295,14 +1328,14 @@ int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy,
         int rc = tune_rows(s, p, depth);
         if (rc) return rc;
     }
-    std::vector<int> plan;
+    PassPlan plan;
     plan_passes(nsteps, cap, !auto_depth, plan);
-    for (size_t k = 0; k < plan.size(); ++k) {
-        const int t = plan[k];
+    for (long k = 0; k < plan.size(); ++k) {
+        const int t = plan.at(k);
         int rc;
         if (t >= 2) {
             const bool last = k + 1 == plan.size();
-            const int nt = last ? 0 : plan[k + 1];
+            const int nt = last ? 0 : plan.at(k + 1);
             rc = pass_fused(s, p, t, nt >= 2 ? nt : 0, last);
         } else {
             rc = pass_single(s, p, g);

@@ -79,3 +79,30 @@ def test_no_cpu_fallback_without_device(csim):
         csim.Field(8, 8)
     with pytest.raises(csim.CsimError):
         csim.Stepper.single(8, 8)
+
+
+def test_pass_schedule_is_a_pure_function_with_the_documented_properties():
+    """csim_pass_schedule: the split of a run into HBM passes of 2..7 time steps (host arithmetic, no GPU).
+    Every rank derives it from (nsteps, smallest tile, fuse) alone, so the checks here hold for all ranks."""
+    pkg = load_package()
+    ps = pkg.pass_schedule
+    assert ps(0) == [] and ps(1) == [1]
+    assert ps(20) == [7, 7, 6]                    # the driver's `bench.py --steps 20`: three launches, not 4 x 5
+    assert ps(36) == [6] * 6 and ps(12) == [6, 6] and ps(13) == [7, 6] and ps(10) == [6, 4]
+    long = ps(1000)
+    assert sum(long) == 1000 and len(long) == 166 and set(long) <= {6, 7} and long[0] == 6
+    for cap in (1, 2, 3, 4, 5, 6, 7, 100):
+        for k in list(range(0, 130)) + [997, 1000, 1001, 4099]:
+            for fuse in (-1, 0, 2, 3, 6, 7):
+                plan = ps(k, cap, fuse)
+                assert sum(plan) == k, (cap, k, fuse)
+                limit = 1 if fuse in (0, 1) else min(cap, 7 if fuse < 0 else fuse)
+                assert all(1 <= t <= max(1, limit) for t in plan), (cap, k, fuse, plan)
+                if limit >= 3 and k >= 2:
+                    assert 1 not in plan, (cap, k, fuse, plan)      # never a single-step pass when avoidable
+                if limit == 2:
+                    assert plan.count(1) <= 1
+                assert plan == sorted(plan[:len(plan)], reverse=True) or fuse >= 0 or k > 48, (cap, k, plan)
+    assert len(ps(10 ** 9)) == 166666666            # planned without materialising anything of that size
+    with pytest.raises(pkg.CsimError):
+        ps(5, 8, 9)
