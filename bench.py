@@ -231,7 +231,7 @@ def main():
     ap.add_argument("--prefetch", type=int, default=0)
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--overlap-mode", type=int, default=-1,
-                    help="N > 1: -1 pick the fastest exchange schedule on this node, 0/1/2 force one")
+                    help="N > 1: -1 pick the fastest exchange schedule on this node, 0..5 force one")
     ap.add_argument("--lds-bytes", type=int, default=0, help="occupancy limiter experiment (see csim.h)")
     ap.add_argument("--fuse", type=int, default=-1,
                     help="time steps per HBM pass: -1 auto (cheapest split of the run into passes of 2..7 steps), 0 off, 2..7")
@@ -359,27 +359,37 @@ def main():
     # non-overlapped timings anyway)
     exchange_modes = None
     if multi and halo == "rccl" and not args.no_overlap and args.overlap_mode < 0:
-        cands = [("overlap-1 frame launch first, exchange under the bulk launch", 1, None),
+        # the stepper's default (5) picks by run length: bulk-first on short runs, merged launches on long ones
+        cands = [("overlap-5 default: bulk-first on runs of < 16 passes, else frame and bulk in one launch", 5, None),
+                 ("overlap-3 frame and bulk in one launch, exchange released by an in-kernel flag", 3, None),
+                 ("overlap-4 bulk launch first hiding this pass's exchange, then the frame launch", 4, None),
+                 ("overlap-1 frame launch first, next pass's exchange under the bulk launch", 1, None),
                  ("overlap-0 exchange not overlapped", 0, None)]
-        try:  # frame + bulk in one launch, comm stream released by a flag the frame wavefronts publish
+        try:
             st.set_option("overlap", 3)
-            cands.insert(0, ("overlap-3 frame and bulk in one launch, exchange released by an in-kernel flag", 3, None))
         except Exception:  # noqa: BLE001  (no hipStreamWaitValue64 / signal memory on this device)
-            pass
+            cands = [c for c in cands if c[1] != 3]
         if os.environ.get("CSIM_BENCH_TRY_OVERLAP2") == "1":
             # the three-stream schedule has only ever run on the self-linked torus of one GPU: opt-in
             cands += [("overlap-2 frame stream beside the bulk, bulk capped at 3 workgroups/CU", 2, 41984),
                       ("overlap-2 frame stream beside the bulk", 2, 0)]
         exchange_modes = {}
-        k2 = 240
+        # trial runs shaped like the timed one (the schedules differ in what a run() call costs at its start):
+        # repetitions of advance(--steps) adding up to >= 240 steps
+        reps = max(1, -(-240 // max(1, args.steps))) if args.steps < 240 else 1
+        k2 = min(args.steps, 240) * reps if args.steps < 240 else 240
         for name, ov, lds in cands:
             st.set_option("overlap", ov)
             if lds is not None:
                 st.set_option("bulk_lds", lds)
-            advance(24)
+            advance(min(args.steps, 24))
             barrier()
             t0 = time.perf_counter()
-            advance(k2)
+            if args.steps < 240:
+                for _ in range(reps):
+                    advance(args.steps)
+            else:
+                advance(240)
             st.sync()
             t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -155,6 +155,7 @@ struct csim_stepper {
     unsigned long long* frame_flag = nullptr;
     unsigned long long pass_no = 0;
     int frame_fence = 0, frame_prio = 1;  // experiment switches of mode 3, see FrameSync
+    bool bulk_first_run = false;          // the current csim_stepper_run uses pass_fused_bulk_first
     // asynchronous snapshot of the interior (device staging copy + pinned host buffer + I/O stream)
     double* snap_d = nullptr;
     double* snap_h = nullptr;
@@ -165,9 +166,11 @@ struct csim_stepper {
     int fuse_cap = 1;     // deepest pass every rank of the decomposition can run (same on all ranks)
     int faces_depth = 0;  // recv2[] holds the neighbours' faces of `cur` of this depth (0 = none)
     SweepCfg cfg;
-    int overlap = 1;        // 0: exchange serial; 1: frame launch, then bulk launch hiding the exchange; 2: + frame of
-                            // the next pass concurrent with the bulk on its own stream (see pass_fused_concurrent);
-                            // 3 (default where signal memory exists): frame and bulk in ONE launch, see pass_fused
+    int overlap = 5;        // 0: exchange serial; 1: frame launch, then bulk launch hiding the NEXT pass's exchange;
+                            // 2: + frame of the next pass concurrent with the bulk on its own stream
+                            // (pass_fused_concurrent); 3: frame and bulk in ONE launch (needs signal memory, else as 1);
+                            // 4: bulk launch first, hiding THIS pass's exchange, then the frame (pass_fused_bulk_first);
+                            // 5 (default): 4 on runs of fewer than SHORT_RUN_PASSES passes, 3 otherwise
     bool frame_async = false;  // the last pass left frame work on s_frame that s_comp has not joined yet
     bool ring_ok = false;      // single rank without a Neumann side: the ghost ring (Dirichlet value / untouched
                                // Periodic ghosts) is constant and both buffers already hold it — no more ghost fills
@@ -555,7 +558,6 @@ int csim_stepper_create(const csim_decomp* dec, double dx, double dy, const int 
                 if (hipExtMallocWithFlags(&p, 8, hipMallocSignalMemory) == hipSuccess) {
                     s->frame_flag = static_cast<unsigned long long*>(p);
                     *s->frame_flag = 0;  // host-visible
-                    s->overlap = 3;      // the default schedule where the device offers it
                 } else {
                     (void)hipGetLastError();
                 }
@@ -1045,8 +1047,63 @@ static int pass_fused_concurrent(csim_stepper* s, const Phys& p, int T, int next
 // FinLines (level T-1 = the state before the last step) and a closing ghost fill turns them into
 // the ghost ring the reference leaves behind — halos and boundary values of the state BEFORE the
 // last step (src/main.cpp:102-104 + src/diffusion.cpp:18-25) — without a trailing one-step pass.
+// Bulk-first pass (overlap 4, and overlap 5 on short runs): the exchange of THIS pass's faces runs under
+// THIS pass's bulk sweep, which needs nothing from the neighbours, and the frame tiles follow once the
+// faces are in:
+//
+//   comm stream     wait(field ready) -> pack faces of `cur` -> RCCL group -> unpack -> ghost fill -> record(recv)
+//   compute stream  BULK tiles -> wait(recv) -> FRAME tiles (-> FinLines on the last pass)
+//
+// No pass of a run — not even the first — waits for an exchange that nothing hides (the frame-first
+// schedules 1 and 3 start the exchange of pass p+1 under pass p, so pass 1 of every csim_stepper_run call
+// pays its exchange in full: ~100 us of a ~160 us pass on the 8-GPU tile).  The price is two launches per
+// pass with the thin frame launch last (~7 us per pass against the merged launch), so it wins on runs
+// of fewer than ~16 passes, e.g. the three passes of a 20-step run.
+static int pass_fused_bulk_first(csim_stepper* s, const Phys& p, int T, bool final_pass) {
+    int kind[4];
+    for (int k = 0; k < 4; ++k) kind[k] = s->phys[k] ? s->bc[k] : 3;
+    GhostArgs g = ghost_args(s);
+    for (int k = 0; k < 4; ++k) g.recv[k] = nullptr;  // neighbour sides come from the deep faces
+    s->pre_unpacked = false;
+    // everything enqueued so far on the compute stream produced `cur` (and the partner buffer's ring)
+    CSIM_HIP(hipEventRecord(s->ev_ready, s->s_comp));
+    CSIM_HIP(hipStreamWaitEvent(s->s_comm, s->ev_ready, 0));
+    int rc = prof_begin(s, T);
+    if (rc) return rc;
+    long comm_slot = -1;
+    rc = prof_start(s, csim_stepper::PROF_COMM, s->s_comm, &comm_slot);
+    if (rc) return rc;
+    CSIM_HIP(launch_halo2_pack(s->cur, s->nx, s->ny, s->pitch, T, s->send2, s->s_comm));
+    rc = post_exchange2(s, T, s->s_comm);
+    if (rc) return rc;
+    CSIM_HIP(launch_halo2_unpack(s->cur, s->nx, s->ny, s->pitch, T, s->recv2, s->s_comm));
+    CSIM_HIP(launch_ghost_fill(s->cur, s->nxt, s->nx, s->ny, s->pitch, g, s->s_comm, T));
+    rc = prof_stop(s, comm_slot, s->s_comm);
+    if (rc) return rc;
+    CSIM_HIP(hipEventRecord(s->ev_recv2, s->s_comm));
+    CSIM_HIP(launch_fused(s, p, kind, T, 2, s->s_comp));  // nothing to launch on tiles that are all frame
+    CSIM_HIP(hipStreamWaitEvent(s->s_comp, s->ev_recv2, 0));
+    CSIM_HIP(launch_fused(s, p, kind, T, 1, s->s_comp, final_pass));
+    rc = prof_end(s);
+    if (rc) return rc;
+    std::swap(s->cur, s->nxt);
+    s->halo_fresh = false;
+    s->faces_depth = 0;
+    if (final_pass) {
+        GhostArgs gf = ghost_args(s);
+        for (int k = 0; k < 4; ++k) {
+            gf.recv[k] = s->phys[k] ? nullptr : s->fin[k];
+            gf.adj[k] = s->phys[k] ? s->fin[k] : nullptr;
+        }
+        CSIM_HIP(launch_ghost_fill(s->cur, s->nxt, s->nx, s->ny, s->pitch, gf, s->s_comp));
+    }
+    return CSIM_OK;
+}
+
 static int pass_fused(csim_stepper* s, const Phys& p, int T, int next_T, bool final_pass = false) {
     const bool rccl = s->multi && !s->external;
+    if (rccl && s->bulk_first_run && s->faces_depth == 0 && !s->frame_async)
+        return pass_fused_bulk_first(s, p, T, final_pass);
     if (rccl && s->overlap == 2 && next_T >= 2 && s->faces_depth == T)
         return pass_fused_concurrent(s, p, T, next_T);
     {
@@ -1079,7 +1136,7 @@ static int pass_fused(csim_stepper* s, const Phys& p, int T, int next_T, bool fi
     int rc = prof_begin(s, T);
     if (rc) return rc;
     if (rccl && s->overlap && next_T >= 2) {
-        if (s->overlap == 3 && s->frame_flag) {
+        if ((s->overlap == 3 || s->overlap == 5) && s->frame_flag) {
             // ONE launch: the frame tiles are the first blocks of the grid, the bulk tiles fill the rest of
             // the chip at once; the last frame wavefront publishes this pass's number and the comm stream,
             // parked on that value by the command processor, starts the exchange under the running kernel
@@ -1105,7 +1162,7 @@ static int pass_fused(csim_stepper* s, const Phys& p, int T, int next_T, bool fi
         CSIM_HIP(launch_halo2_pack(s->nxt, s->nx, s->ny, s->pitch, next_T, s->send2, s->s_comm));
         rc = post_exchange2(s, next_T, s->s_comm);
         if (rc) return rc;
-        if (s->overlap == 1 || s->overlap == 3) {
+        if (s->overlap == 1 || s->overlap == 3 || s->overlap == 5) {
             // the comm stream goes on to prepare the next pass — unpack of the faces into the new
             // field's halo cells, ghost fill of both buffers' rings — while the bulk is still
             // sweeping: those cells are disjoint from everything the bulk reads or writes, and
@@ -1117,7 +1174,7 @@ static int pass_fused(csim_stepper* s, const Phys& p, int T, int next_T, bool fi
         rc = prof_stop(s, comm_slot, s->s_comm);
         if (rc) return rc;
         CSIM_HIP(hipEventRecord(s->ev_recv2, s->s_comm));
-        if (!(s->overlap == 3 && s->frame_flag)) CSIM_HIP(launch_fused(s, p, kind, T, 2, s->s_comp));
+        if (!((s->overlap == 3 || s->overlap == 5) && s->frame_flag)) CSIM_HIP(launch_fused(s, p, kind, T, 2, s->s_comp));
         s->faces_depth = next_T;
     } else {
         CSIM_HIP(launch_fused(s, p, kind, T, 0, s->s_comp, final_pass));
@@ -1219,6 +1276,7 @@ static int fused_depth(const csim_stepper* s) {
 // depends on (K, cap) only, so every rank of a decomposition derives the same schedule.
 static const double STEP_COST[MAX_FUSE + 1] = {0.0, 4.52, 2.32, 1.55, 1.206, 1.09, 1.0, 1.005};
 static const double PASS_COST = 0.05;
+static const long SHORT_RUN_PASSES = 16;  // overlap 5: runs of fewer passes go bulk-first (see pass_fused_bulk_first)
 // The plan is `lead` passes of depth `lead_depth` followed by the passes listed in `tail` (a run of 10^9
 // steps must not materialise 10^8 entries).
 struct PassPlan {
@@ -1330,6 +1388,10 @@ int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy,
     }
     PassPlan plan;
     plan_passes(nsteps, cap, !auto_depth, plan);
+    // exchange schedule of this run: bulk-first where asked for, or (overlap 5) on runs too short to
+    // amortise the one exchange per call that the frame-first schedules cannot hide
+    s->bulk_first_run = s->multi && !s->external &&
+                        (s->overlap == 4 || (s->overlap == 5 && plan.size() < SHORT_RUN_PASSES));
     for (long k = 0; k < plan.size(); ++k) {
         const int t = plan.at(k);
         int rc;
@@ -1383,7 +1445,7 @@ int csim_stepper_set_option(csim_stepper* s, const char* key, long value) {
     } else if (k == "xcd_swizzle") {
         s->cfg.xcd_swizzle = value != 0;
     } else if (k == "overlap") {
-        CSIM_REQUIRE(value >= 0 && value <= 3, "overlap must be 0, 1, 2 or 3");
+        CSIM_REQUIRE(value >= 0 && value <= 5, "overlap must be 0..5");
         if (value == 3 && s->multi && !s->frame_flag)
             return fail(CSIM_ERR_STATE, "overlap 3 needs hipStreamWaitValue64 / signal memory, which this device or runtime refused");
         s->overlap = static_cast<int>(value);

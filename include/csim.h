@@ -188,11 +188,14 @@ int csim_stepper_sum(csim_stepper* s, double* out);
  *   "variant"        single-step kernel family: 0 auto, 1 dpp, 2 lds, 3 naive
  *   "rows_per_chunk" rows one wavefront marches per launch (0 auto), "prefetch" (single-step kernel)
  *   "xcd_swizzle"    0/1 XCD-aware block->tile map
- *   "overlap"        0 serial exchange, 1 (default) frame tiles first and the exchange under the bulk sweep,
- *                    2 additionally the next frame on its own stream beside the bulk ("bulk_lds": dynamic LDS
- *                    per bulk workgroup as an occupancy cap, 0 = none), 3 frame and bulk in ONE launch: the
- *                    frame wavefronts publish a flag the comm stream waits on (hipStreamWaitValue64), so the
- *                    exchange starts under the running kernel without an event or a second launch
+ *   "overlap"        exchange schedule of a multi-rank run (all bit-identical): 0 serial exchange; 1 frame launch
+ *                    first, the NEXT pass's exchange under the bulk launch; 2 additionally the next frame on its
+ *                    own stream beside the bulk ("bulk_lds": dynamic LDS per bulk workgroup as an occupancy cap,
+ *                    0 = none); 3 frame and bulk in ONE launch: the frame wavefronts publish a flag the comm
+ *                    stream waits on (hipStreamWaitValue64), so the exchange starts under the running kernel
+ *                    without an event or a second launch (without signal memory: as 1); 4 bulk launch first with
+ *                    THIS pass's exchange under it, then the frame launch — no pass of a run, not even the first,
+ *                    waits for an unhidden exchange; 5 (default) = 4 on runs of fewer than 16 passes, 3 otherwise
  *   "external_halo"  0/1 the caller carries the faces (csim_stepper_halo_* / _faces_*)
  *   "profile"        0 off, k >= 1: HIP events around the sweep launch(es) of every k-th pass
  *                    (csim_stepper_kernel_time)

@@ -17,6 +17,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shape", nargs="+", default=["8192x16384", "8192x8192", "4096x8192"])
     ap.add_argument("--steps", type=int, default=1200)
+    ap.add_argument("--run", type=int, default=0, help="steps per csim_stepper_run call (0 = all of --steps in one call)")
     ap.add_argument("--modes", nargs="+", default=["single", "torus-overlap", "torus-merged", "torus-concurrent",
                                                    "torus-concurrent-nolds", "torus-serial"])
     args = ap.parse_args()
@@ -37,7 +38,7 @@ def main():
                     st.set_option(k, int(v))
             else:
                 st.comm_init(csim.comm_unique_id())
-                st.set_option("overlap", {"torus-overlap": 1, "torus-serial": 0, "torus-merged": 3}.get(mode.split("+")[0], 2))
+                st.set_option("overlap", {"torus-overlap": 1, "torus-serial": 0, "torus-merged": 3, "torus-bulkfirst": 4, "torus-auto": 5}.get(mode.split("+")[0], 2))
                 for tok in mode.split("+")[1:]:   # e.g. torus-merged+frame_fence=1+frame_prio=0
                     k, v = tok.split("=")
                     st.set_option(k, int(v))
@@ -51,11 +52,15 @@ def main():
             best = 1e9
             for _ in range(3):
                 t0 = time.perf_counter()
-                st.run(0.05, 0.1, 0.5, 0.25, args.steps)
+                if args.run > 0:   # many short runs back to back, like a driver loop between snapshots
+                    for _ in range(args.steps // args.run):
+                        st.run(0.05, 0.1, 0.5, 0.25, args.run)
+                else:
+                    st.run(0.05, 0.1, 0.5, 0.25, args.steps)
                 st.sync()
                 best = min(best, time.perf_counter() - t0)
             st.close()
-            print(json.dumps(dict(tile=sh, mode=mode, ms_per_step=best / args.steps * 1e3,
+            print(json.dumps(dict(tile=sh, mode=mode, steps_per_run=args.run or args.steps, ms_per_step=best / args.steps * 1e3,
                                   mcells=nx * ny * args.steps / best / 1e6)), flush=True)
 
 
