@@ -231,7 +231,7 @@ def main():
     ap.add_argument("--prefetch", type=int, default=0)
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--overlap-mode", type=int, default=-1,
-                    help="N > 1: -1 pick the fastest exchange schedule on this node, 0..5 force one")
+                    help="N > 1: -1 pick the fastest exchange schedule on this node; 0, 1, 3, 4, 5 force one")
     ap.add_argument("--lds-bytes", type=int, default=0, help="occupancy limiter experiment (see csim.h)")
     ap.add_argument("--fuse", type=int, default=-1,
                     help="time steps per HBM pass: -1 auto (cheapest split of the run into passes of 2..7 steps), 0 off, 2..7")
@@ -360,28 +360,22 @@ def main():
     exchange_modes = None
     if multi and halo == "rccl" and not args.no_overlap and args.overlap_mode < 0:
         # the stepper's default (5) picks by run length: bulk-first on short runs, merged launches on long ones
-        cands = [("overlap-5 default: bulk-first on runs of < 16 passes, else frame and bulk in one launch", 5, None),
-                 ("overlap-3 frame and bulk in one launch, exchange released by an in-kernel flag", 3, None),
-                 ("overlap-4 bulk launch first hiding this pass's exchange, then the frame launch", 4, None),
-                 ("overlap-1 frame launch first, next pass's exchange under the bulk launch", 1, None),
-                 ("overlap-0 exchange not overlapped", 0, None)]
+        cands = [("overlap-5 default: bulk-first on runs of < 16 passes, else frame and bulk in one launch", 5),
+                 ("overlap-3 frame and bulk in one launch, exchange released by an in-kernel flag", 3),
+                 ("overlap-4 bulk launch first hiding this pass's exchange, then the frame launch", 4),
+                 ("overlap-1 frame launch first, next pass's exchange under the bulk launch", 1),
+                 ("overlap-0 exchange not overlapped", 0)]
         try:
             st.set_option("overlap", 3)
         except Exception:  # noqa: BLE001  (no hipStreamWaitValue64 / signal memory on this device)
             cands = [c for c in cands if c[1] != 3]
-        if os.environ.get("CSIM_BENCH_TRY_OVERLAP2") == "1":
-            # the three-stream schedule has only ever run on the self-linked torus of one GPU: opt-in
-            cands += [("overlap-2 frame stream beside the bulk, bulk capped at 3 workgroups/CU", 2, 41984),
-                      ("overlap-2 frame stream beside the bulk", 2, 0)]
         exchange_modes = {}
         # trial runs shaped like the timed one (the schedules differ in what a run() call costs at its start):
         # repetitions of advance(--steps) adding up to >= 240 steps
         reps = max(1, -(-240 // max(1, args.steps))) if args.steps < 240 else 1
         k2 = min(args.steps, 240) * reps if args.steps < 240 else 240
-        for name, ov, lds in cands:
+        for name, ov in cands:
             st.set_option("overlap", ov)
-            if lds is not None:
-                st.set_option("bulk_lds", lds)
             advance(min(args.steps, 24))
             barrier()
             t0 = time.perf_counter()
@@ -397,11 +391,9 @@ def main():
         best = min(exchange_modes, key=exchange_modes.get)
         if exchange_modes[best] > 0.98 * exchange_modes[cands[0][0]]:
             best = cands[0][0]  # within noise of the default schedule: keep the default
-        for name, ov, lds in cands:
+        for name, ov in cands:
             if name == best:
                 st.set_option("overlap", ov)
-                if lds is not None:
-                    st.set_option("bulk_lds", lds)
         exchange_modes["chosen"] = best
     elif multi and args.overlap_mode >= 0:
         st.set_option("overlap", args.overlap_mode)

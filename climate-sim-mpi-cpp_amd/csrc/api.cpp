@@ -135,7 +135,6 @@ struct csim_stepper {
     double* recv[4]{nullptr, nullptr, nullptr, nullptr};
     double* fin[4]{nullptr, nullptr, nullptr, nullptr};  // FinLines of the last fused pass of a run (all sides)
     hipStream_t s_comp = nullptr, s_comm = nullptr;
-    hipStream_t s_frame = nullptr;  // high priority: frame tiles + face packing of a fused multi-rank pass
     hipEvent_t ev_edge = nullptr, ev_recv = nullptr, ev_ready = nullptr;
     ncclComm_t comm = nullptr;
     bool multi = false;       // has at least one neighbour
@@ -167,17 +166,13 @@ struct csim_stepper {
     int faces_depth = 0;  // recv2[] holds the neighbours' faces of `cur` of this depth (0 = none)
     SweepCfg cfg;
     int overlap = 5;        // 0: exchange serial; 1: frame launch, then bulk launch hiding the NEXT pass's exchange;
-                            // 2: + frame of the next pass concurrent with the bulk on its own stream
-                            // (pass_fused_concurrent); 3: frame and bulk in ONE launch (needs signal memory, else as 1);
+                            // 3: frame and bulk in ONE launch (needs signal memory, else as 1);
                             // 4: bulk launch first, hiding THIS pass's exchange, then the frame (pass_fused_bulk_first);
                             // 5 (default): 4 on runs of fewer than SHORT_RUN_PASSES passes, 3 otherwise
-    bool frame_async = false;  // the last pass left frame work on s_frame that s_comp has not joined yet
     bool ring_ok = false;      // single rank without a Neumann side: the ghost ring (Dirichlet value / untouched
                                // Periodic ghosts) is constant and both buffers already hold it — no more ghost fills
     bool pre_unpacked = false; // the comm stream already unpacked the faces in recv2[] and filled the ghosts
                                // for the next fused pass (ev_recv2 marks the end of that)
-    int bulk_lds = 41984;      // mode 2: dynamic LDS per bulk workgroup = 3 instead of 4 workgroups per CU, so
-                               // that frame and RCCL workgroups always find a free slot
     int fuse = -1;  // time steps per HBM pass: -1 auto (cheapest split, see plan_passes), 0/1 off, 2..7 depth
     int contract = 0;  // 1: opt-in contracted arithmetic (5-point FMA stencil), NOT bit-identical to the reference
     int external = 0;  // halos are carried by the caller (csim_stepper_halo_pack/_unpack), not RCCL
@@ -534,11 +529,10 @@ int csim_stepper_create(const csim_decomp* dec, double dx, double dy, const int 
             ok(hipMemset(s->send2[d], 0, n)) && ok(hipMemset(s->recv2[d], 0, n));
     }
     if (e == hipSuccess) {
-        // the exchange and the frame tiles that feed it go on high-priority streams, so they are
-        // dispatched ahead of the bulk sweep that is hiding them
+        // the exchange goes on a high-priority stream, so its small kernels are dispatched ahead of the
+        // bulk sweep that is hiding them
         int lo = 0, hi = 0;  // numerically lower = higher priority
         ok(hipDeviceGetStreamPriorityRange(&lo, &hi)) &&
-            ok(hipStreamCreateWithPriority(&s->s_frame, hipStreamNonBlocking, hi)) &&
             ok(hipStreamCreateWithPriority(&s->s_comm, hipStreamNonBlocking, hi));
     }
     if (e == hipSuccess) {
@@ -581,7 +575,6 @@ int csim_stepper_destroy(csim_stepper* s) {
     if (!s) return CSIM_OK;
     if (s->s_comp) (void)hipStreamSynchronize(s->s_comp);
     if (s->s_comm) (void)hipStreamSynchronize(s->s_comm);
-    if (s->s_frame) (void)hipStreamSynchronize(s->s_frame);
     if (s->s_io) (void)hipStreamSynchronize(s->s_io);
     if (s->snap_d) (void)hipFree(s->snap_d);
     if (s->snap_h) (void)hipHostFree(s->snap_h);
@@ -607,7 +600,6 @@ int csim_stepper_destroy(csim_stepper* s) {
     if (s->ev_recv) (void)hipEventDestroy(s->ev_recv);
     if (s->s_comp) (void)hipStreamDestroy(s->s_comp);
     if (s->s_comm) (void)hipStreamDestroy(s->s_comm);
-    if (s->s_frame) (void)hipStreamDestroy(s->s_frame);
     if (s->ev_ready) (void)hipEventDestroy(s->ev_ready);
     if (s->buf[0]) (void)hipFree(s->buf[0]);
     if (s->buf[1]) (void)hipFree(s->buf[1]);
@@ -932,15 +924,10 @@ static int prof_end(csim_stepper* s) {
     return rc;
 }
 
-static int join_frame(csim_stepper* s);
 
 // ONE reference step: exchange_halos + apply_boundary + fused sweep + swap
 static int pass_single(csim_stepper* s, const Phys& p, const GhostArgs& g) {
     const bool rccl = s->multi && !s->external;
-    {
-        int rc = join_frame(s);
-        if (rc) return rc;
-    }
     if (rccl) {
         if (!s->halo_fresh) {
             int rc = refresh_halos(s);  // on s_comp: ordered before the ghost fill
@@ -989,58 +976,6 @@ static hipError_t launch_fused(csim_stepper* s, const Phys& p, const int kind[4]
     cfg.rows_used = &s->last_rows;
     return launch_sweepO(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, cfg, kind, s->bc_value, T, part, st,
                          final_pass ? s->fin : nullptr, sync);
-}
-
-// s_comp waits for the frame work a concurrent pass left on s_frame (no-op otherwise)
-static int join_frame(csim_stepper* s) {
-    if (s->frame_async) {
-        CSIM_HIP(hipStreamWaitEvent(s->s_comp, s->ev_edge2, 0));
-        s->frame_async = false;
-    }
-    return CSIM_OK;
-}
-
-// Steady-state pass of a multi-rank run in overlap mode 2.  What needs the neighbours' faces is
-// only the FRAME; the BULK of pass p depends on nothing but pass p-1.  So the bulk sweeps run back
-// to back on the compute stream, while unpack + ghost fill + frame of the same pass run on the
-// (high-priority) frame stream as soon as the exchange has delivered, concurrently with the bulk:
-//
-//   compute stream  record(B[p-1]) -> wait(F[p-1]) -> BULK[p]
-//   frame stream    wait(B[p-1]), wait(X[p-1]) -> unpack -> ghost fill -> FRAME[p] -> record(F[p])
-//   comm stream     wait(F[p]) -> pack faces of pass p+1 -> RCCL exchange -> record(X[p])
-//
-// The bulk is launched with a dynamic-LDS request that caps it at 3 workgroups per CU, so the frame
-// (and the RCCL kernel) always find wavefront slots instead of queueing behind ~100 us bulk tiles.
-// Requires the faces of depth T to be in flight already (the previous pass exchanged them).
-static int pass_fused_concurrent(csim_stepper* s, const Phys& p, int T, int next_T) {
-    int kind[4];
-    for (int k = 0; k < 4; ++k) kind[k] = s->phys[k] ? s->bc[k] : 3;
-    GhostArgs g = ghost_args(s);
-    for (int k = 0; k < 4; ++k) g.recv[k] = nullptr;
-    // everything enqueued on the compute stream so far: BULK[p-1] (or the whole previous pass)
-    CSIM_HIP(hipEventRecord(s->ev_ready, s->s_comp));
-    if (s->frame_async) CSIM_HIP(hipStreamWaitEvent(s->s_comp, s->ev_edge2, 0));  // FRAME[p-1]
-    int rc = prof_begin(s, T);
-    if (rc) return rc;
-    CSIM_HIP(launch_fused(s, p, kind, T, 2, s->s_comp, false, s->bulk_lds));
-    rc = prof_end(s);
-    if (rc) return rc;
-    CSIM_HIP(hipStreamWaitEvent(s->s_frame, s->ev_ready, 0));
-    CSIM_HIP(hipStreamWaitEvent(s->s_frame, s->ev_recv2, 0));  // X[p-1]: the faces this pass consumes
-    CSIM_HIP(launch_halo2_unpack(s->cur, s->nx, s->ny, s->pitch, T, s->recv2, s->s_frame));
-    CSIM_HIP(launch_ghost_fill(s->cur, s->nxt, s->nx, s->ny, s->pitch, g, s->s_frame, T));
-    CSIM_HIP(launch_fused(s, p, kind, T, 1, s->s_frame));
-    CSIM_HIP(hipEventRecord(s->ev_edge2, s->s_frame));
-    CSIM_HIP(hipStreamWaitEvent(s->s_comm, s->ev_edge2, 0));
-    CSIM_HIP(launch_halo2_pack(s->nxt, s->nx, s->ny, s->pitch, next_T, s->send2, s->s_comm));
-    rc = post_exchange2(s, next_T, s->s_comm);
-    if (rc) return rc;
-    CSIM_HIP(hipEventRecord(s->ev_recv2, s->s_comm));
-    s->faces_depth = next_T;
-    s->frame_async = true;
-    std::swap(s->cur, s->nxt);
-    s->halo_fresh = false;
-    return CSIM_OK;
 }
 
 // final_pass (overlapped-strip kernels only): the last pass of a run.  The kernel also emits the
@@ -1102,14 +1037,8 @@ static int pass_fused_bulk_first(csim_stepper* s, const Phys& p, int T, bool fin
 
 static int pass_fused(csim_stepper* s, const Phys& p, int T, int next_T, bool final_pass = false) {
     const bool rccl = s->multi && !s->external;
-    if (rccl && s->bulk_first_run && s->faces_depth == 0 && !s->frame_async)
+    if (rccl && s->bulk_first_run && s->faces_depth == 0)
         return pass_fused_bulk_first(s, p, T, final_pass);
-    if (rccl && s->overlap == 2 && next_T >= 2 && s->faces_depth == T)
-        return pass_fused_concurrent(s, p, T, next_T);
-    {
-        int rc = join_frame(s);
-        if (rc) return rc;
-    }
     int kind[4];
     for (int k = 0; k < 4; ++k) kind[k] = s->phys[k] ? s->bc[k] : 3;
     GhostArgs g = ghost_args(s);
@@ -1404,14 +1333,13 @@ int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy,
         }
         if (rc) return rc;
     }
-    return join_frame(s);
+    return CSIM_OK;
 }
 
 int csim_stepper_sync(csim_stepper* s) {
     CSIM_REQUIRE(s, "null stepper");
     CSIM_HIP(hipStreamSynchronize(s->s_comp));
     CSIM_HIP(hipStreamSynchronize(s->s_comm));
-    CSIM_HIP(hipStreamSynchronize(s->s_frame));
     return CSIM_OK;
 }
 
@@ -1445,7 +1373,7 @@ int csim_stepper_set_option(csim_stepper* s, const char* key, long value) {
     } else if (k == "xcd_swizzle") {
         s->cfg.xcd_swizzle = value != 0;
     } else if (k == "overlap") {
-        CSIM_REQUIRE(value >= 0 && value <= 5, "overlap must be 0..5");
+        CSIM_REQUIRE(value >= 0 && value <= 5 && value != 2, "overlap must be 0, 1, 3, 4 or 5");
         if (value == 3 && s->multi && !s->frame_flag)
             return fail(CSIM_ERR_STATE, "overlap 3 needs hipStreamWaitValue64 / signal memory, which this device or runtime refused");
         s->overlap = static_cast<int>(value);
@@ -1454,9 +1382,6 @@ int csim_stepper_set_option(csim_stepper* s, const char* key, long value) {
         s->frame_fence = static_cast<int>(value);
     } else if (k == "frame_prio") {
         s->frame_prio = value != 0;
-    } else if (k == "bulk_lds") {
-        CSIM_REQUIRE(value >= 0 && value <= 65536, "bulk_lds must be 0..65536");
-        s->bulk_lds = static_cast<int>(value);
     } else if (k == "external_halo") {
         s->external = value != 0;
         s->halo_fresh = false;

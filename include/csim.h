@@ -189,9 +189,7 @@ int csim_stepper_sum(csim_stepper* s, double* out);
  *   "rows_per_chunk" rows one wavefront marches per launch (0 auto), "prefetch" (single-step kernel)
  *   "xcd_swizzle"    0/1 XCD-aware block->tile map
  *   "overlap"        exchange schedule of a multi-rank run (all bit-identical): 0 serial exchange; 1 frame launch
- *                    first, the NEXT pass's exchange under the bulk launch; 2 additionally the next frame on its
- *                    own stream beside the bulk ("bulk_lds": dynamic LDS per bulk workgroup as an occupancy cap,
- *                    0 = none); 3 frame and bulk in ONE launch: the frame wavefronts publish a flag the comm
+ *                    first, the NEXT pass's exchange under the bulk launch; 3 frame and bulk in ONE launch: the frame wavefronts publish a flag the comm
  *                    stream waits on (hipStreamWaitValue64), so the exchange starts under the running kernel
  *                    without an event or a second launch (without signal memory: as 1); 4 bulk launch first with
  *                    THIS pass's exchange under it, then the frame launch — no pass of a run, not even the first,

@@ -39,13 +39,13 @@ def test_bench_line_contract_single_gpu():
 
 
 def test_bench_multi_rank_path_on_self_linked_torus():
-    r = run_bench([], env={"CSIM_BENCH_SELF_TORUS": "1", "CSIM_BENCH_TRY_OVERLAP2": "1"})
+    r = run_bench([], env={"CSIM_BENCH_SELF_TORUS": "1"})
     cfg = r["config"]
     assert cfg["halo_transport"] == "rccl"
     sched = cfg["exchange_schedules_ms_per_step"]
-    # overlap 5 (default), 3 (merged launch), 4 (bulk-first), 1, 0 and the two opt-in overlap-2 variants, + "chosen"
-    assert sched["chosen"] in sched and len(sched) == 8 and all(any(k.startswith(f"overlap-{m}") for k in sched)
-                                                                for m in (0, 1, 2, 3, 4, 5))
+    # overlap 5 (default), 3 (merged launch), 4 (bulk-first), 1, 0, + "chosen"
+    assert sched["chosen"] in sched and len(sched) == 6 and all(any(k.startswith(f"overlap-{m}") for k in sched)
+                                                                for m in (0, 1, 3, 4, 5))
     pr = cfg["per_rank"]
     assert len(pr) == 1 and pr[0]["rank"] == 0 and pr[0]["kernel_avg_ms"] > 0 and pr[0]["neighbours"] == [0, 0, 0, 0]
     assert cfg["relative_mass_drift"] < 1e-9  # a lost or misplaced face would leak mass at the seams

@@ -52,7 +52,7 @@ def self_neighbor_decomp(csim, nx, ny, sides):
 # sides are {left,right} and/or {bottom,top}
 @pytest.mark.parametrize("sides,bc", [((1, 1, 1, 1), "dddd"), ((1, 1, 0, 0), "ddnd"),
                                       ((0, 0, 1, 1), "npdd"), ((1, 1, 0, 0), "ddpp")])
-@pytest.mark.parametrize("overlap", [1, 0, 2, 3, 4, 5])
+@pytest.mark.parametrize("overlap", [1, 0, 3, 4, 5])
 @pytest.mark.parametrize("shape", [(300, 170, 7), (256, 170, 9), (1024, 300, 12), (128, 2, 8)])
 def test_self_exchange_torus(csim, sides, bc, overlap, shape):
     # fused passes across "ranks": deep faces and corner blocks in 8 directions, frame tiles first,
@@ -88,7 +88,7 @@ def test_self_exchange_torus(csim, sides, bc, overlap, shape):
 def test_torus_at_tile_scale_every_schedule_equals_the_oracle(csim):
     """a per-GPU-tile-sized torus (many strips x many chunks, so the frame / bulk split and the
     8-direction deep faces are all in play): every exchange schedule — serial single steps, the
-    overlapped 6-step passes, the three-stream mode — must reproduce the ORACLE's torus bit for bit."""
+    overlapped 6-step passes, merged and bulk-first launches — must reproduce the ORACLE's torus bit for bit."""
     nx, ny, steps = 2048, 4096, 44
     D, vx, vy, dt = 0.1, -0.5, 0.25, 0.1
     d = self_neighbor_decomp(csim, nx, ny, (1, 1, 1, 1))
@@ -98,8 +98,6 @@ def test_torus_at_tile_scale_every_schedule_equals_the_oracle(csim):
     assert want[0, 0] > 0 and want[-1, -1] > 0 and want[0, -1] > 0 and want[-1, 0] > 0
     for opts in [dict(overlap=0, fuse=0), dict(overlap=1, fuse=-1), dict(overlap=0, fuse=-1),
                  dict(overlap=1, fuse=4, rows_per_chunk=64), dict(overlap=1, fuse=3), dict(overlap=1, fuse=5),
-                 dict(overlap=2, fuse=-1), dict(overlap=2, fuse=4, rows_per_chunk=64),
-                 dict(overlap=2, fuse=5, bulk_lds=0),
                  dict(overlap=3, fuse=-1), dict(overlap=3, fuse=5, rows_per_chunk=40), dict(overlap=3, fuse=2),
                  dict(overlap=4, fuse=-1), dict(overlap=4, fuse=7), dict(overlap=5, fuse=-1), dict(overlap=4, fuse=3)]:
         st = csim.Stepper(d, 1.0, 1.0, csim.bc_codes("dddd"))
@@ -114,7 +112,7 @@ def test_torus_at_tile_scale_every_schedule_equals_the_oracle(csim):
 
 
 @pytest.mark.parametrize("sides,bc", [((1, 1, 0, 0), "ddnp"), ((0, 0, 1, 1), "pndd"), ((1, 1, 0, 0), "ddnn")])
-@pytest.mark.parametrize("overlap", [1, 2, 0, 3, 4, 5])
+@pytest.mark.parametrize("overlap", [1, 0, 3, 4, 5])
 def test_torus_mixed_physical_and_linked_sides_depth6(csim, sides, bc, overlap):
     """linked sides next to physical Neumann / Periodic sides on a tile tall and wide enough for the
     frame / bulk split, three 6-step passes (overlapped exchange, comm-stream pre-unpack + ghost fill

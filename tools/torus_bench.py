@@ -18,8 +18,8 @@ def main():
     ap.add_argument("--shape", nargs="+", default=["8192x16384", "8192x8192", "4096x8192"])
     ap.add_argument("--steps", type=int, default=1200)
     ap.add_argument("--run", type=int, default=0, help="steps per csim_stepper_run call (0 = all of --steps in one call)")
-    ap.add_argument("--modes", nargs="+", default=["single", "torus-overlap", "torus-merged", "torus-concurrent",
-                                                   "torus-concurrent-nolds", "torus-serial"])
+    ap.add_argument("--modes", nargs="+", default=["single", "torus-auto", "torus-merged", "torus-bulkfirst",
+                                                   "torus-overlap", "torus-serial"])
     args = ap.parse_args()
     csim = load_package()
     csim.lib()
@@ -38,12 +38,10 @@ def main():
                     st.set_option(k, int(v))
             else:
                 st.comm_init(csim.comm_unique_id())
-                st.set_option("overlap", {"torus-overlap": 1, "torus-serial": 0, "torus-merged": 3, "torus-bulkfirst": 4, "torus-auto": 5}.get(mode.split("+")[0], 2))
+                st.set_option("overlap", {"torus-overlap": 1, "torus-serial": 0, "torus-merged": 3, "torus-bulkfirst": 4, "torus-auto": 5}[mode.split("+")[0]])
                 for tok in mode.split("+")[1:]:   # e.g. torus-merged+frame_fence=1+frame_prio=0
                     k, v = tok.split("=")
                     st.set_option(k, int(v))
-                if mode == "torus-concurrent-nolds":
-                    st.set_option("bulk_lds", 0)
             st.init_gaussian()
             t0 = time.perf_counter()
             while time.perf_counter() - t0 < 0.3:  # leave the idle clocks (and let the stepper tune its chunking)

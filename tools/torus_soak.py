@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tools/torus_soak.py [STEPS] — long consistency run of the multi-rank schedules on the self-linked
-torus (one GPU): serial exchange, overlap 1 and overlap 2 (with and without the occupancy cap) must
+torus (one GPU): serial exchange, frame-first (1), merged (3), bulk-first (4) and the default (5) must
 leave bit-identical fields after thousands of steps (a stream-ordering race would show up as a
 mismatch), in runs cut into uneven pieces so that pass depths and final passes vary."""
 import os
@@ -18,7 +18,8 @@ csim.set_device(0)
 ok = True
 for nx, ny, bc, sides in ((2048, 4096, "dddd", (1, 1, 1, 1)), (4096, 1024, "dndn", (1, 1, 0, 0)), (1000, 3000, "nnpd", (0, 0, 1, 1))):
     ref = None
-    for opts in (dict(overlap=0), dict(overlap=1), dict(overlap=2), dict(overlap=2, bulk_lds=0), dict(overlap=1, fuse=4)):
+    for opts in (dict(overlap=0), dict(overlap=1), dict(overlap=3), dict(overlap=4), dict(overlap=5), dict(overlap=4, fuse=7),
+                 dict(overlap=1, fuse=4)):
         d = csim.decomp_init(1, 0, nx, ny)
         for k in range(4):
             d.nbr[k] = 0 if sides[k] else csim.NO_NEIGHBOR

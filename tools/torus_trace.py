@@ -21,7 +21,7 @@ if mode != "single":
 st = csim.Stepper(d, 1.0, 1.0, csim.bc_codes("dddd"))
 if mode != "single":
     st.comm_init(csim.comm_unique_id())
-    st.set_option("overlap", {"torus-overlap": 1, "torus-serial": 0, "torus-merged": 3}.get(mode, 2))
+    st.set_option("overlap", {"torus-overlap": 1, "torus-serial": 0, "torus-merged": 3, "torus-bulkfirst": 4, "torus-auto": 5}[mode])
 st.init_gaussian()
 t0 = time.perf_counter()
 while time.perf_counter() - t0 < 0.3:
