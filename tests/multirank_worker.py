@@ -10,6 +10,8 @@ src/halo.cpp:28-43.  Two engines step the local tile:
                          (several ranks may share one GPU; RCCL refuses that, gloo does not)
   --engine hip-external{2..7}  GPU: same, but 2..7 steps per call (one fused pass) with faces
                          of that depth in 8 directions (csim_stepper_faces_pack/_unpack)
+  --engine hip-rccl[N]   GPUs: one rank per GPU, halos over RCCL (exchange schedule N); only where
+                         at least as many GPUs as ranks are visible
 Rank 0 gathers the global interior and compares it bit-for-bit with the golden fixture."""
 import argparse
 import json
@@ -102,6 +104,24 @@ def main():
             st.halo_unpack(exchange(st.halo_pack(), nbr))
             st.run(m["D"], dt, m["vx"], m["vy"], 1)
             remaining -= 1
+        local = st.download()
+        st.close()
+    elif args.engine.startswith("hip-rccl"):
+        # one rank per GPU, halos over RCCL point-to-point (needs as many visible GPUs as ranks); the suffix
+        # selects the exchange schedule ("hip-rccl" = the stepper's default, "hip-rccl3" = overlap 3, ...)
+        csim.lib()
+        ndev = csim.device_count()
+        assert ndev >= world, f"{world} ranks need {world} GPUs, {ndev} visible"
+        csim.set_device(rank)
+        st = csim.Stepper(dec, m["dx"], m["dy"], bc)
+        box = [csim.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        st.comm_init(box[0])
+        if args.engine[-1].isdigit():
+            st.set_option("overlap", int(args.engine[-1]))
+        st.upload(u)
+        st.run(m["D"], dt, m["vx"], m["vy"], 1)                    # uneven calls: single step, fused passes
+        st.run(m["D"], dt, m["vx"], m["vy"], m["steps"] - 1)
         local = st.download()
         st.close()
     else:
