@@ -1005,6 +1005,8 @@ static int pass_fused_bulk_first(csim_stepper* s, const Phys& p, int T, bool fin
     CSIM_HIP(hipStreamWaitEvent(s->s_comm, s->ev_ready, 0));
     int rc = prof_begin(s, T);
     if (rc) return rc;
+    // the bulk goes out first: the GPU starts on it while the host is still enqueuing the exchange
+    CSIM_HIP(launch_fused(s, p, kind, T, 2, s->s_comp));  // nothing to launch on tiles that are all frame
     long comm_slot = -1;
     rc = prof_start(s, csim_stepper::PROF_COMM, s->s_comm, &comm_slot);
     if (rc) return rc;
@@ -1016,7 +1018,6 @@ static int pass_fused_bulk_first(csim_stepper* s, const Phys& p, int T, bool fin
     rc = prof_stop(s, comm_slot, s->s_comm);
     if (rc) return rc;
     CSIM_HIP(hipEventRecord(s->ev_recv2, s->s_comm));
-    CSIM_HIP(launch_fused(s, p, kind, T, 2, s->s_comp));  // nothing to launch on tiles that are all frame
     CSIM_HIP(hipStreamWaitEvent(s->s_comp, s->ev_recv2, 0));
     CSIM_HIP(launch_fused(s, p, kind, T, 1, s->s_comp, final_pass));
     rc = prof_end(s);
