@@ -119,6 +119,35 @@ def test_driver_mpi_ranks_window_the_netcdf_ic(tmp_path, case, np_ranks, dims):
     assert f"dims={dims}" in out
 
 
+@pytest.mark.skipif(not os.path.exists(MPIRUN), reason="no mpirun in this image")
+def test_driver_config5_shape_at_4101x4099_four_mpi_ranks(tmp_path):
+    """BASELINE configs[4] end to end at a size the oracle finishes in seconds: all-Neumann, the IC loaded
+    from a NetCDF file by four MPI ranks that each read only their block (remainder tiles: 2050 + 2051 columns,
+    2049 + 2050 rows), faces over MPI once per fused pass, 24 steps; the snapshot record of the state before
+    step 24 must equal the oracle's 4-tile run bit for bit."""
+    from oracle import cpu_oracle as ora
+    exe = os.path.join(DRV, "climate_sim_hip_mpi")
+    if not os.path.exists(exe):
+        pytest.skip("MPI flavour not built")
+    nx, ny, steps = 4101, 4099, 24
+    u0 = ora.gaussian_global(nx, ny, sigma_frac=0.07)[1:-1, 1:-1] + 0.05 * np.random.default_rng(5).random((ny, nx))
+    raw = tmp_path / "ic.bin"
+    np.ascontiguousarray(u0).tofile(raw)
+    ic = tmp_path / "ic.nc"
+    subprocess.run([os.path.join(DRV, "csim_hosttool"), "nc-write", str(ic), str(raw), "1", f"--nx={nx}", f"--ny={ny}"],
+                   check=True)
+    m = dict(nx=nx, ny=ny, dx=1.0, dy=1.0, D=0.05, vx=0.5, vy=0.25, dt=0.1, bc="nnnn", sigma_frac=0.05)
+    out, h = run_driver(tmp_path, "climate_sim_hip_mpi", m, steps + 1, steps, launcher=(MPIRUN, "-np", "4"),
+                        extra=("--halo=mpi", "--ic.mode=file", f"--ic.path={ic}"))
+    assert "dims=2x2" in out
+    rec = records(h, m)
+    assert rec.shape[0] == 2 and np.array_equal(rec[0], u0)
+    w = ora.World(4, nx, ny)
+    w.scatter(np.ascontiguousarray(u0))
+    w.run(m["D"], m["vx"], m["vy"], m["dt"], ora.bc_codes("nnnn"), steps, threads=4)
+    assert np.array_equal(rec[1], w.gather())
+
+
 def test_driver_rejects_bad_ic(tmp_path):
     """reference tests/simulation/integration/integration_boundary_error.cpp: a bad IC preset gives
     a non-zero exit and no output file."""
