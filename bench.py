@@ -337,6 +337,14 @@ def main():
         st.sync()
         if multi:
             dist.barrier()
+            # a gloo barrier releases the ranks up to a few hundred microseconds apart — a sixth of a 20-step
+            # timed region at 8 GPUs, which the first halo exchange would then spend waiting for the last rank.
+            # All ranks sit on one node and CLOCK_MONOTONIC is system-wide: agree on a start time 3 ms ahead
+            # and spin up to it, so that every rank enters the timed region within a microsecond of the others.
+            box = [time.perf_counter() + 0.003 if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            while time.perf_counter() < box[0]:
+                pass
 
     # untimed: clock ramp (also triggers the stepper's one-off rows-per-chunk trial), then W warm-up steps
     ramp_steps = 0
