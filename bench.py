@@ -524,6 +524,9 @@ def main():
                 executed_frac=executed / FP64_VALU_PEAK_TOPS,
                 redundancy_executed_over_useful=executed / useful_tops,
                 sustained_clock_ghz_under_counters=valu.get("clock_ghz"),
+                # SIMD-quad-cycles of the launch = GRBM_GUI_ACTIVE / 8 XCDs / 4 x 1024 SIMDs; ACTIVE_INST_VALU counts quad-cycles
+                valu_busy_frac_under_counters=(valu["SQ_ACTIVE_INST_VALU"] / (valu["GRBM_GUI_ACTIVE"] / 8.0 / 4.0 * 1024.0))
+                if valu.get("SQ_ACTIVE_INST_VALU") and valu.get("GRBM_GUI_ACTIVE") else None,
                 source=f"profiles/sq_valu.json ({valu.get('kernel')}, {valu.get('nx')}x{valu.get('ny')}): SQ_INSTS_VALU "
                        f"per launch, {fp64_share:.3f} of them fp64 add/mul (rest: DPP lane shifts), clock = "
                        f"GRBM_GUI_ACTIVE / 8 / kernel time in that PMC run")
