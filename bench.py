@@ -233,6 +233,7 @@ def main():
     ap.add_argument("--overlap-mode", type=int, default=-1,
                     help="N > 1: -1 pick the fastest exchange schedule on this node; 0, 1, 3, 4, 5 force one")
     ap.add_argument("--lds-bytes", type=int, default=0, help="occupancy limiter experiment (see csim.h)")
+    ap.add_argument("--tail-split", type=int, default=-1, help="0/1: half-height chunks at the end of a whole-field launch (default: on)")
     ap.add_argument("--fuse", type=int, default=-1,
                     help="time steps per HBM pass: -1 auto (cheapest split of the run into passes of 2..7 steps), 0 off, 2..7")
     args = ap.parse_args()
@@ -308,6 +309,8 @@ def main():
         st.set_option("contract", args.contract)
     if args.lds_bytes:
         st.set_option("lds_bytes", args.lds_bytes)
+    if args.tail_split >= 0:
+        st.set_option("tail_split", args.tail_split)
     st.init_gaussian(1.0, 0.05, 0.5, 0.5)
     dt = min(PHYS["dt"], csim.safe_dt(1.0, 1.0, PHYS["vx"], PHYS["vy"], PHYS["D"]))
 

@@ -1373,6 +1373,11 @@ int csim_stepper_set_option(csim_stepper* s, const char* key, long value) {
         s->cfg.prefetch = static_cast<int>(value);
     } else if (k == "xcd_swizzle") {
         s->cfg.xcd_swizzle = value != 0;
+    } else if (k == "tail_split") {
+        CSIM_REQUIRE(value >= 0 && value <= 2, "tail_split must be 0, 1 or 2");
+        s->cfg.tail_split = static_cast<int>(value);
+        s->tuned = false;  // the best chunk height depends on it
+        s->cfg.tuned_rows = 0;
     } else if (k == "overlap") {
         CSIM_REQUIRE(value >= 0 && value <= 5 && value != 2, "overlap must be 0, 1, 3, 4 or 5");
         if (value == 3 && s->multi && !s->frame_flag)
@@ -1424,6 +1429,7 @@ int csim_stepper_get_option(const csim_stepper* s, const char* key, long* value)
     else if (k == "last_rows") *value = s->last_rows;
     else if (k == "prefetch") *value = s->cfg.prefetch;
     else if (k == "xcd_swizzle") *value = s->cfg.xcd_swizzle;
+    else if (k == "tail_split") *value = s->cfg.tail_split;
     else if (k == "overlap") *value = s->overlap;
     else if (k == "external_halo") *value = s->external;
     else if (k == "fuse") *value = s->fuse;

@@ -67,6 +67,8 @@ struct SweepCfg {
                              // (41 KB -> 3 workgroups per CU instead of 4), the kernel never touches it
     int prefetch = 0;        // 0 = auto (rows kept in flight per wavefront)
     int xcd_swizzle = 1;
+    int tail_split = 1;        // fused launches of two or more rounds of wavefronts end with a region of half-height
+                               // chunks (see Tiling); 0 off, 2 experiment (half + quarter height)
     int* rows_used = nullptr;  // out: chunk height of the last whole-field / bulk launch (option "last_rows")
 };
 

@@ -449,12 +449,18 @@ struct TileRegion {
     int j0, j1, ry;     // rows j0 .. j1 in chunks of ry
 };
 struct Tiling {
-    TileRegion r[5];
+    TileRegion r[8];
     int nregions, ntiles;
     // merged launch (frame + bulk in one grid): tiles [0, frame_tiles) are the frame, owned by blocks
     // [0, frame_blocks) in plain order so that they are dispatched first and spread over all XCDs; the
     // bulk tiles follow from tile 4 * frame_blocks on, XCD-remapped among themselves.  0 = not merged.
     int frame_tiles, frame_blocks;
+    // TAIL region: the last tail_blocks blocks own, in plain order, the tiles of the last region(s) — the top
+    // eighth of the (bulk of the) field cut into chunks of half the height, dispatched last, so that the
+    // chip drains in half-height steps instead of idling behind the last full-height wavefronts
+    // (17 468 wavefronts are 4.26 rounds of 4096 slots on 16384^2: the partial last round was 7 % of the
+    // launch).  The main tiles before them fill their blocks exactly and are XCD-remapped.  0 = no tail.
+    int tail_blocks;
 };
 
 template <int DIV, int T, int SX, int SY>
@@ -471,24 +477,25 @@ __global__ __launch_bounds__(256) void k_sweepO_dpp(const double* __restrict__ i
 #ifdef CSIM_TRACE
     WaveTrace trace_scope(blockIdx.x * 4 + wave, lane);
 #endif
+    // blocks [0, frame_blocks): the frame tiles in plain order; the last tail_blocks blocks: the tail tiles in
+    // plain order; the blocks in between own the main tiles, XCD-remapped among themselves
     int tile;
     bool frame_tile = false;
-    if (tl.frame_blocks > 0) {
+    {
         const int b = blockIdx.x;
         if (b < tl.frame_blocks) {
             tile = 4 * b + wave;
             if (tile >= tl.frame_tiles) return;  // padding of the last frame block
             frame_tile = true;
         } else {
-            tile = tl.frame_tiles + xcd_remap(b - tl.frame_blocks, gridDim.x - tl.frame_blocks, swz) * 4 + wave;
+            const int lb = b - tl.frame_blocks, nb_mid = gridDim.x - tl.frame_blocks - tl.tail_blocks;
+            tile = tl.frame_tiles + (lb < nb_mid ? xcd_remap(lb, nb_mid, swz) : lb) * 4 + wave;
         }
-    } else {
-        tile = xcd_remap(blockIdx.x, gridDim.x, swz) * 4 + wave;
     }
     if (tile >= tl.ntiles) return;  // wave-uniform
     int t0 = 0, strip0 = tl.r[0].strip0, nstrip = tl.r[0].nstrip, j0 = tl.r[0].j0, j1 = tl.r[0].j1, ry = tl.r[0].ry;
 #pragma unroll
-    for (int q = 1; q < 5; ++q)
+    for (int q = 1; q < 8; ++q)
         if (q < tl.nregions && tile >= tl.r[q - 1].t_end) {
             t0 = tl.r[q - 1].t_end;
             strip0 = tl.r[q].strip0, nstrip = tl.r[q].nstrip, j0 = tl.r[q].j0, j1 = tl.r[q].j1, ry = tl.r[q].ry;
@@ -1067,8 +1074,34 @@ static hipError_t sweepO_div(const double* in, double* out, int nx, int ny, int 
         tl.ntiles += nstrip * cdiv(j1 - j0 + 1, rows);
         r.t_end = tl.ntiles;
     };
+    // rows j0..j1 of `nstrip` strips: full-height chunks, or — on launches of two or more rounds of wavefronts —
+    // a main region of 7/8 of the chunks (a multiple of four, so that its tiles fill whole blocks whatever the
+    // number of strips) followed by a tail region at half the height; returns the tail tiles
+    auto add_rows = [&](int strip0, int nstrip, int j0, int j1, int rows) -> int {
+        const int nrows = j1 - j0 + 1;
+        if (nstrip <= 0 || nrows <= 0) return 0;
+        const int nchunks = cdiv(nrows, rows);
+        if (!cfg.tail_split || rows < 48 || nchunks < 16 || static_cast<long>(nstrip) * nchunks < 8192) {
+            add(strip0, nstrip, j0, j1, rows);
+            return 0;
+        }
+        auto snap = [&](int r) { return r + (6 - (r + 2 * (T - 1)) % 6) % 6; };
+        const bool two_level = cfg.tail_split != 2;  // default: 7/8 of the chunks full height + the rest at half height;
+                                                     // 2 (experiment): 3/4 + half + quarter height — measured no better
+        const int main_chunks = (nchunks * (two_level ? 7 : 3) / (two_level ? 8 : 4)) / 4 * 4;
+        const int j_main = j0 + main_chunks * rows - 1;
+        const int half = snap(rows / 2), quarter = snap(rows / 4);
+        const int rest = j1 - j_main;                       // rows left for the tail regions
+        const int j_half = two_level ? j1 : j_main + (rest * 2 / 3) / half * half;  // about two thirds of them at half height
+        add(strip0, nstrip, j0, j_main, rows);
+        const int before = tl.ntiles;
+        add(strip0, nstrip, j_main + 1, j_half, half);
+        add(strip0, nstrip, j_half + 1, j1, quarter);
+        return tl.ntiles - before;
+    };
+    int tail_tiles = 0;
     if (part == 0 || ((part == 1 || part == 3) && !split)) {
-        add(0, nstrips, 1, ny, ry);
+        tail_tiles = add_rows(0, nstrips, 1, ny, ry);
     } else if (part == 1 || part == 3) {
         add(0, nstrips, 1, hf, hf);
         add(0, nstrips, ny - hf + 1, ny, hf);
@@ -1076,23 +1109,27 @@ static hipError_t sweepO_div(const double* in, double* out, int nx, int ny, int 
         add(nstrips - nright, nright, hf + 1, ny - hf, hf);
     }
     int nblocks;
-    if (part == 3) {  // merged launch: the frame tiles above, then the bulk in the same grid
+    if (part == 3 && split) {  // merged launch: the frame tiles above, then the bulk in the same grid
         tl.frame_tiles = tl.ntiles;
         tl.frame_blocks = cdiv(tl.ntiles, 4);
         fs.nframe = static_cast<unsigned>(tl.frame_tiles);
-        int bulk_tiles = 0;
-        if (split) {
-            const int before = tl.ntiles;
-            add(1, nstrips - 1 - nright, hf + 1, ny - hf, std::min(ry, ny - 2 * hf));
-            bulk_tiles = tl.ntiles - before;
-        }
-        nblocks = tl.frame_blocks + cdiv(bulk_tiles, 4);
+        const int before = tl.ntiles;
+        tail_tiles = add_rows(1, nstrips - 1 - nright, hf + 1, ny - hf, std::min(ry, ny - 2 * hf));
+        nblocks = tl.frame_blocks + cdiv(tl.ntiles - before, 4);
+    } else if (part == 3) {  // a tile that is all frame: every tile counts for the flag
+        tl.frame_tiles = tl.ntiles;
+        tl.frame_blocks = cdiv(tl.ntiles, 4);
+        tl.tail_blocks = 0;
+        tail_tiles = 0;
+        fs.nframe = static_cast<unsigned>(tl.frame_tiles);
+        nblocks = tl.frame_blocks;
     } else {
-        if (part == 2 && split) add(1, nstrips - 1 - nright, hf + 1, ny - hf, std::min(ry, ny - 2 * hf));
+        if (part == 2 && split) tail_tiles = add_rows(1, nstrips - 1 - nright, hf + 1, ny - hf, std::min(ry, ny - 2 * hf));
         if (tl.ntiles == 0) return hipSuccess;  // part 2 of a field that is all frame
         nblocks = cdiv(tl.ntiles, 4);
         fs = FrameSync{};
     }
+    tl.tail_blocks = cdiv(tail_tiles, 4);
     const dim3 grid(nblocks), block(256);
     const int sw = cfg.xcd_swizzle;
     const int sign = (p.vx >= 0.0 ? 2 : 0) + (p.vy >= 0.0 ? 1 : 0);

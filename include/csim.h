@@ -187,7 +187,8 @@ int csim_stepper_sum(csim_stepper* s, double* out);
  *                    1000 = 166 x 6 + 4, 20 = 7 + 7 + 6), 0/1 off, 2..7 balanced passes of at most that depth
  *   "variant"        single-step kernel family: 0 auto, 1 dpp, 2 lds, 3 naive
  *   "rows_per_chunk" rows one wavefront marches per launch (0 auto), "prefetch" (single-step kernel)
- *   "xcd_swizzle"    0/1 XCD-aware block->tile map
+ *   "xcd_swizzle"    0/1 XCD-aware block->tile map; "tail_split" 0/1 (default 1): launches of two or more rounds of
+ *                    wavefronts end with the top eighth of the rows in half-height chunks, dispatched last
  *   "overlap"        exchange schedule of a multi-rank run (all bit-identical): 0 serial exchange; 1 frame launch
  *                    first, the NEXT pass's exchange under the bulk launch; 3 frame and bulk in ONE launch: the frame wavefronts publish a flag the comm
  *                    stream waits on (hipStreamWaitValue64), so the exchange starts under the running kernel
