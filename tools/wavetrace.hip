@@ -63,7 +63,8 @@ int main(int argc, char** argv) {
     const int nstrips = (nx + stride - 1) / stride;
     const int nchunks = (ny + ry - 1) / ry;
     const int nblocks = (nstrips * nchunks + 3) / 4;
-    const size_t nwaves = static_cast<size_t>(nblocks) * 4;
+    // (trace slots: a launch with a tail region of half-height chunks has more tiles than strips x chunks)
+    const size_t nwaves = static_cast<size_t>(nblocks) * 4 * 2 + 64;
     unsigned long long* d_tr;
     CK(hipMalloc(&d_tr, nwaves * 3 * sizeof(unsigned long long)));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_wave_trace), &d_tr, sizeof(d_tr)));
