@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--nx", type=int, default=16384)
     ap.add_argument("--ny", type=int, default=16384)
     ap.add_argument("--bcs", nargs="+", default=["dddd", "nnnn"])
-    ap.add_argument("--rows", type=int, nargs="+", default=[110, 122, 134, 146, 158])
+    ap.add_argument("--rows", type=int, nargs="+", default=[110, 134, 158, 182, 206, 230])
     ap.add_argument("--passes", type=int, default=4)
     args = ap.parse_args()
     csim = load_package()
