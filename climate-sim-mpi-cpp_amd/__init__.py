@@ -137,7 +137,7 @@ def lib() -> C.CDLL:
         "csim_stepper_faces_unpack": (i, [vp, i, C.POINTER(dp)]),
         "csim_stepper_run": (i, [vp, d, d, d, d, i]),
         "csim_stepper_tune": (i, [vp, d, d, d, d]),
-        "csim_pass_schedule": (i, [i, i, i, ip, i, C.POINTER(C.c_long)]),
+        "csim_pass_schedule": (i, [i, i, C.c_long, i, ip, i, C.POINTER(C.c_long)]),
         "csim_stepper_sync": (i, [vp]),
         "csim_stepper_minmax": (i, [vp, dp]),
         "csim_stepper_sum": (i, [vp, dp]),
@@ -224,12 +224,12 @@ def exchange_plan(dec: Decomp, depth: int):
             [(m.peer, m.dir, m.count) for m in recvs[:nr.value]])
 
 
-def pass_schedule(nsteps: int, smallest_tile: int = 1 << 30, fuse: int = -1):
+def pass_schedule(nsteps: int, smallest_tile: int = 1 << 30, fuse: int = -1, tile_cells: int = 0):
     """time steps per HBM pass of a run of nsteps (csim_pass_schedule), as a list"""
     n = C.c_long(0)
-    _ck(lib().csim_pass_schedule(nsteps, min(smallest_tile, 1 << 30), fuse, None, 0, C.byref(n)))
+    _ck(lib().csim_pass_schedule(nsteps, min(smallest_tile, 1 << 30), tile_cells, fuse, None, 0, C.byref(n)))
     buf = (C.c_int * max(1, n.value))()
-    _ck(lib().csim_pass_schedule(nsteps, min(smallest_tile, 1 << 30), fuse, buf, n.value, C.byref(n)))
+    _ck(lib().csim_pass_schedule(nsteps, min(smallest_tile, 1 << 30), tile_cells, fuse, buf, n.value, C.byref(n)))
     return list(buf[:n.value])
 
 

@@ -162,6 +162,7 @@ struct csim_stepper {
     hipEvent_t ev_snap_src = nullptr, ev_snap_copied = nullptr;
     bool snap_pending = false;
     int last_rows = 0;    // chunk height the last fused whole-field / bulk launch used
+    long tile_cells = 0;  // cells of the decomposition's base tile (same on every rank): picks the preferred depth
     int fuse_cap = 1;     // deepest pass every rank of the decomposition can run (same on all ranks)
     int faces_depth = 0;  // recv2[] holds the neighbours' faces of `cur` of this depth (0 = none)
     SweepCfg cfg;
@@ -516,6 +517,7 @@ int csim_stepper_create(const csim_decomp* dec, double dx, double dy, const int 
         const int px = dec->dims[0] > 0 ? dec->dims[0] : 1, py = dec->dims[1] > 0 ? dec->dims[1] : 1;
         const int gx = dec->nx_global > 0 ? dec->nx_global : s->nx, gy = dec->ny_global > 0 ? dec->ny_global : s->ny;
         const int bx = gx / px, by = gy / py;
+        s->tile_cells = static_cast<long>(s->multi ? bx : s->nx) * (s->multi ? by : s->ny);
         const int min_tile = s->multi ? std::min(bx, by) : MAX_FUSE;
         s->fuse_cap = std::max(1, std::min(MAX_FUSE, min_tile));
     }
@@ -1201,9 +1203,9 @@ static int tune_rows(csim_stepper* s, const Phys& p, int T) {
 }
 
 // depth of the fused passes of this stepper with the current options (1 = single steps only): what
-// the option "fuse" asks for, or PREF_FUSE — the depth with the lowest cost per step — in auto mode
+// the option "fuse" asks for, or pref_fuse(tile) — the depth with the lowest cost per step — in auto mode
 static int fused_depth(const csim_stepper* s) {
-    const int depth = std::min(s->fuse < 0 ? PREF_FUSE : s->fuse, s->fuse_cap);
+    const int depth = std::min(s->fuse < 0 ? pref_fuse(s->tile_cells) : s->fuse, s->fuse_cap);
     const bool dpp_family = s->cfg.variant == VAR_AUTO || s->cfg.variant == VAR_DPP;
     return depth >= 2 && dpp_family ? depth : 1;
 }
@@ -1212,12 +1214,14 @@ static int fused_depth(const csim_stepper* s) {
 // the cheapest split by a small dynamic programme over the measured cost of one time step inside a pass
 // of depth T relative to T = 6 (16384^2, DESIGN.md §7: shallow passes are HBM-bound and cost almost as much
 // as a deep one: T = 5 costs 9 % more per step than T = 6; T = 7 pays 12.5 % instead of 9.4 % overlap columns
-// but moves fewer bytes per step and measures 0.4 % above T = 6, so it is used where it saves a whole pass:
-// 20 steps = 7 + 7 + 6 instead of 4 x 5, +11 %) plus a small fixed cost per pass.  A run of
+// but moves fewer bytes per step: 0.9 % cheaper than T = 6 on tiles of >= 2e8 cells, 6 % dearer on small ones,
+// where it is still used when it saves a whole pass: 20 steps = 7 + 7 + 6 instead of 4 x 5) plus a small fixed
+// cost per pass.  A run of
 // two or more steps never contains a single-step pass unless it must (tiles only two cells deep and an odd
 // K): one step alone costs 4.5 steps of a deep pass, so the programme avoids it by itself.  The result
 // depends on (K, cap) only, so every rank of a decomposition derives the same schedule.
-static const double STEP_COST[MAX_FUSE + 1] = {0.0, 4.52, 2.32, 1.55, 1.206, 1.09, 1.0, 1.005};
+static const double STEP_COST[MAX_FUSE + 1] = {0.0, 4.52, 2.32, 1.55, 1.206, 1.09, 1.0, 1.06};
+static const double STEP_COST_BIG[MAX_FUSE + 1] = {0.0, 4.52, 2.32, 1.55, 1.24, 1.09, 1.0, 0.991};  // tiles >= BIG_TILE_CELLS
 static const double PASS_COST = 0.05;
 static const long SHORT_RUN_PASSES = 16;  // overlap 5: runs of fewer passes go bulk-first (see pass_fused_bulk_first)
 // The plan is `lead` passes of depth `lead_depth` followed by the passes listed in `tail` (a run of 10^9
@@ -1229,7 +1233,8 @@ struct PassPlan {
     long size() const { return lead + static_cast<long>(tail.size()); }
     int at(long k) const { return k < lead ? lead_depth : tail[static_cast<size_t>(k - lead)]; }
 };
-static void plan_passes(int K, int cap, bool balanced, PassPlan& plan) {
+static void plan_passes(int K, int cap, bool balanced, long tile_cells, PassPlan& plan) {
+    const double* step_cost = tile_cells >= BIG_TILE_CELLS ? STEP_COST_BIG : STEP_COST;
     plan = PassPlan{};
     std::vector<int>& out = plan.tail;
     if (K <= 0) return;
@@ -1253,7 +1258,7 @@ static void plan_passes(int K, int cap, bool balanced, PassPlan& plan) {
         }
         return;
     }
-    const int pref = std::min(cap, PREF_FUSE);
+    const int pref = std::min(cap, pref_fuse(tile_cells));
     // long runs: passes of the preferred depth, the last <= 8 * pref steps are planned
     if (K > 8 * pref) plan.lead = (K - 8 * pref + pref - 1) / pref;
     plan.lead_depth = pref;
@@ -1264,7 +1269,7 @@ static void plan_passes(int K, int cap, bool balanced, PassPlan& plan) {
     for (int k = 1; k <= R; ++k)
         for (int t = 1; t <= std::min(cap, k); ++t) {
             if (t == 1 && cap >= 3 && K >= 2) continue;  // every k >= 2 splits into 2s and 3s: no single-step pass
-            const double c = best[static_cast<size_t>(k - t)] + t * STEP_COST[t] + PASS_COST;
+            const double c = best[static_cast<size_t>(k - t)] + t * step_cost[t] + PASS_COST;
             if (c < best[static_cast<size_t>(k)]) {
                 best[static_cast<size_t>(k)] = c;
                 pick[static_cast<size_t>(k)] = t;
@@ -1278,15 +1283,16 @@ static void plan_passes(int K, int cap, bool balanced, PassPlan& plan) {
 
 // the pass schedule as pure host arithmetic (no GPU): what csim_stepper_run(nsteps) will launch on a
 // decomposition whose smallest tile is `smallest_tile` cells deep, with option "fuse" = `fuse`
-int csim_pass_schedule(int nsteps, int smallest_tile, int fuse, int* depths, int max_depths, long* npasses) {
+int csim_pass_schedule(int nsteps, int smallest_tile, long tile_cells, int fuse, int* depths, int max_depths,
+                       long* npasses) {
     CSIM_REQUIRE(npasses && nsteps >= 0 && smallest_tile >= 1, "bad argument");
     CSIM_REQUIRE(fuse >= -1 && fuse <= MAX_FUSE, "fuse must be -1 (auto) or 0..7");
     CSIM_REQUIRE(max_depths == 0 || depths, "depths is null");
     const int fuse_cap = std::max(1, std::min(MAX_FUSE, smallest_tile));
-    const int depth = std::min(fuse < 0 ? PREF_FUSE : fuse, fuse_cap);
+    const int depth = std::min(fuse < 0 ? pref_fuse(tile_cells) : fuse, fuse_cap);
     const int cap = depth < 2 ? 1 : fuse < 0 ? std::min(MAX_FUSE, fuse_cap) : depth;
     PassPlan plan;
-    plan_passes(nsteps, cap, fuse >= 0, plan);
+    plan_passes(nsteps, cap, fuse >= 0, tile_cells, plan);
     *npasses = plan.size();
     for (long k = 0; k < plan.size() && k < max_depths; ++k) depths[k] = plan.at(k);
     return CSIM_OK;
@@ -1330,7 +1336,7 @@ int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy,
         if (rc) return rc;
     }
     PassPlan plan;
-    plan_passes(nsteps, cap, !auto_depth, plan);
+    plan_passes(nsteps, cap, !auto_depth, s->tile_cells, plan);
     // exchange schedule of this run: bulk-first where asked for, or (overlap 5) on runs too short to
     // amortise the one exchange per call that the frame-first schedules cannot hide
     s->bulk_first_run = s->multi && !s->external &&

@@ -406,7 +406,7 @@ def test_full_field_16384_exactly_what_bench_times(csim, bc, ic):
     very launches bench.py times: a 36-step run (>= 4 x depth, so the on-device chunk-height trial fires
     and the six passes are k_sweepO_dpp<T=6> with the tuned rows), then 20 more steps on the same
     stepper (7 + 7 + 6: two passes of k_sweepO_dpp<T=7> and one of <T=6> with the tuned rows re-snapped —
-    the schedule of the driver's `bench.py --steps 20`), then 10 more (6 + 4).  Oracle: 16 tiles / 16 threads of oracle/cpu_stepper.c
+    the schedule of the driver's `bench.py --steps 20`), then 10 more (5 + 5).  Oracle: 16 tiles / 16 threads of oracle/cpu_stepper.c
     (= the reference under mpirun -np 16), reassembled with its physical ghost lines."""
     n = 16384
     D, vx, vy, dt = 0.05, 0.5, 0.25, 0.1      # bench.py PHYS
@@ -422,7 +422,7 @@ def test_full_field_16384_exactly_what_bench_times(csim, bc, ic):
     del u0
     st.set_option("profile", 1)
     done = 0
-    for steps, passes in [(36, {6: 6}), (20, {7: 2, 6: 1}), (10, {6: 1, 4: 1})]:
+    for steps, passes in [(36, {6: 6}), (20, {7: 2, 6: 1}), (10, {5: 2})]:
         st.reset_timers()
         st.run(D, dt, vx, vy, steps)
         got = st.download()
