@@ -1222,6 +1222,7 @@ static int fused_depth(const csim_stepper* s) {
 // depends on (K, cap) only, so every rank of a decomposition derives the same schedule.
 static const double STEP_COST[MAX_FUSE + 1] = {0.0, 4.52, 2.32, 1.55, 1.206, 1.09, 1.0, 1.06};
 static const double STEP_COST_BIG[MAX_FUSE + 1] = {0.0, 4.52, 2.32, 1.55, 1.24, 1.09, 1.0, 0.991};  // tiles >= BIG_TILE_CELLS
+static const double STEP_COST_SMALL[MAX_FUSE + 1] = {0.0, 3.0, 1.5, 1.03, 1.0, 1.0, 1.2, 1.22};    // tiles < SMALL_TILE_CELLS (relative to T = 4)
 static const double PASS_COST = 0.05;
 static const long SHORT_RUN_PASSES = 16;  // overlap 5: runs of fewer passes go bulk-first (see pass_fused_bulk_first)
 // The plan is `lead` passes of depth `lead_depth` followed by the passes listed in `tail` (a run of 10^9
@@ -1234,7 +1235,8 @@ struct PassPlan {
     int at(long k) const { return k < lead ? lead_depth : tail[static_cast<size_t>(k - lead)]; }
 };
 static void plan_passes(int K, int cap, bool balanced, long tile_cells, PassPlan& plan) {
-    const double* step_cost = tile_cells >= BIG_TILE_CELLS ? STEP_COST_BIG : STEP_COST;
+    const double* step_cost = tile_cells >= BIG_TILE_CELLS ? STEP_COST_BIG
+                              : (tile_cells > 0 && tile_cells < SMALL_TILE_CELLS) ? STEP_COST_SMALL : STEP_COST;
     plan = PassPlan{};
     std::vector<int>& out = plan.tail;
     if (K <= 0) return;

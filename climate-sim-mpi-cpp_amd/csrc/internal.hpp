@@ -97,10 +97,15 @@ hipError_t launch_sweepO(const double* in, double* out, int nx, int ny, int pitc
                          hipStream_t st, double* const fin_lines[4] = nullptr, const FrameSync* sync = nullptr);
 constexpr int MAX_FUSE = 7;       // deepest temporal blocking (123 VGPRs: still 4 waves/SIMD; 8 would drop to 3)
 // depth with the lowest measured cost per time step (tools/depth_ab.py, profiles/r02_depth_ab.jsonl): 7 on tiles
-// of >= 2e8 cells (+0.9 % over 6 at 16384^2 and 32768^2), 6 below (7 loses 7 % on a 4096 x 8192 tile, which is a
-// single round of wavefronts: more overhead rows per chunk and nothing to amortise them)
+// of >= 2e8 cells (+0.9 % over 6 at 16384^2 and 32768^2); 6 in between (7 loses 7 % on a 4096 x 8192 tile, which is
+// a single round of wavefronts: more overhead rows per chunk and nothing to amortise them); 4 on tiles below
+// 1.2e7 cells, where a launch is a fraction of one round and the length of a wavefront's dependent chain
+// decides (+17...22 % over 6 at 512^2, 1024^2, 3072^2)
 constexpr long BIG_TILE_CELLS = 200000000L;
-inline int pref_fuse(long tile_cells) { return tile_cells >= BIG_TILE_CELLS ? 7 : 6; }
+constexpr long SMALL_TILE_CELLS = 12000000L;
+inline int pref_fuse(long tile_cells) {
+    return tile_cells >= BIG_TILE_CELLS ? 7 : (tile_cells > 0 && tile_cells < SMALL_TILE_CELLS) ? 4 : 6;
+}
 constexpr int GHOST_EXTRA = 6;    // device-only ghost layers beyond the reference's one (= MAX_FUSE-1)
 // faces of depth H = 2..6 (8 directions: L R B T BL BR TL TR; nullptr = no neighbour there);
 // sizes H*(ny+2) (L,R), H*(nx+2) (B,T), H*H (corners)

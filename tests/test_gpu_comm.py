@@ -96,7 +96,7 @@ def test_torus_at_tile_scale_every_schedule_equals_the_oracle(csim):
     u0 = ora.gaussian_global(nx, ny, sigma_frac=0.02, xc_frac=0.03, yc_frac=0.97)
     want = torus_oracle(u0, 1.0, 1.0, D, vx, vy, dt, steps)[1:-1, 1:-1]
     assert want[0, 0] > 0 and want[-1, -1] > 0 and want[0, -1] > 0 and want[-1, 0] > 0
-    for opts in [dict(overlap=0, fuse=0), dict(overlap=1, fuse=-1), dict(overlap=0, fuse=-1),
+    for opts in [dict(overlap=0, fuse=0), dict(overlap=1, fuse=-1), dict(overlap=0, fuse=-1), dict(overlap=1, fuse=6), dict(overlap=3, fuse=6),
                  dict(overlap=1, fuse=4, rows_per_chunk=64), dict(overlap=1, fuse=3), dict(overlap=1, fuse=5),
                  dict(overlap=3, fuse=-1), dict(overlap=3, fuse=5, rows_per_chunk=40), dict(overlap=3, fuse=2),
                  dict(overlap=4, fuse=-1), dict(overlap=4, fuse=7), dict(overlap=5, fuse=-1), dict(overlap=4, fuse=3)]:
@@ -129,6 +129,7 @@ def test_torus_mixed_physical_and_linked_sides_depth6(csim, sides, bc, overlap):
     st = csim.Stepper(self_neighbor_decomp(csim, nx, ny, sides), 1.0, 1.0, codes)
     st.comm_init(csim.comm_unique_id())
     st.set_option("overlap", overlap)
+    st.set_option("fuse", 6)          # (auto would take depth 4 on a tile this small)
     st.set_option("profile", 1)
     st.upload(u0)
     st.run(D, dt, vx, vy, steps)
