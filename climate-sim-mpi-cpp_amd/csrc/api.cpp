@@ -1139,7 +1139,7 @@ static int tune_rows(csim_stepper* s, const Phys& p, int T) {
     // would cost more than it can win
     if (static_cast<long>(s->nx) * s->ny < (1L << 22)) return CSIM_OK;
     std::vector<int> cand;
-    for (int ry = 14; ry <= 236 && ry <= s->ny; ry += 6) {
+    for (int ry = 6; ry <= 236 && ry <= s->ny; ry += (ry < 30 ? 4 : 6)) {
         const int snapped = ry + (6 - (ry + 2 * (T - 1)) % 6) % 6;
         if (snapped <= s->ny && (cand.empty() || cand.back() != snapped)) cand.push_back(snapped);
     }

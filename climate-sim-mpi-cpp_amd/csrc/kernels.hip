@@ -1051,6 +1051,10 @@ static hipError_t sweepO_div(const double* in, double* out, int nx, int ny, int 
         } else {
             ry = 64;
             while (ry > 16 && static_cast<long>(nstrips) * cdiv(ny, ry) < 8192) ry >>= 1;
+            // tiles too small for the on-device trial (< 4 M cells): a launch is at most a round or two of
+            // wavefronts and the length of a wavefront's march decides — the shortest chunks win although
+            // they double the overhead rows (512^2: +52 %, 1024^2: +37 %, 2048^2: +25 % against 18 rows)
+            if (static_cast<long>(nx) * ny < (1L << 22)) ry = 6;
         }
         // the march runs whole groups of six iterations: make ry + 2 (T - 1) a multiple of six so
         // that only a ragged last chunk computes surplus rows
