@@ -551,6 +551,171 @@ __global__ __launch_bounds__(256) void k_sweepO_dpp(const double* __restrict__ i
     }
 }
 
+// ============================================================================================
+// launcher of the overlapped-strip sweep (templates; see the split-build note below)
+// ============================================================================================
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+template <int DIV, int T>
+hipError_t sweepO_div(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
+                             const SweepCfg& cfg, const Bc2& bc, const FinLines& fin, int part, hipStream_t st,
+                             FrameSync fs) {
+    constexpr int STRIDE = OverlapGeom<T>::STRIDE;
+    const int nstrips = cdiv(nx, STRIDE);
+    int ry = cfg.rows_per_chunk;
+    if (ry <= 0) {
+        if (cfg.tuned_rows > 0) {
+            ry = cfg.tuned_rows;
+        } else {
+            ry = 64;
+            while (ry > 16 && static_cast<long>(nstrips) * cdiv(ny, ry) < 8192) ry >>= 1;
+            // tiles too small for the on-device trial (< 4 M cells): a launch is at most a round or two of
+            // wavefronts and the length of a wavefront's march decides — the shortest chunks win although
+            // they double the overhead rows (512^2: +52 %, 1024^2: +37 %, 2048^2: +25 % against 18 rows)
+            if (static_cast<long>(nx) * ny < (1L << 22)) ry = 6;
+        }
+        // the march runs whole groups of six iterations: make ry + 2 (T - 1) a multiple of six so
+        // that only a ragged last chunk computes surplus rows
+        ry += (6 - (ry + 2 * (T - 1)) % 6) % 6;
+    }
+    if (ry > ny) ry = ny;
+    if (cfg.rows_used && part != 1) *cfg.rows_used = ry;
+    // part 0: the whole field.  part 1 / 2 (multi-rank pass): FRAME / BULK.  The frame is the
+    // bottom and top bands (hf rows, all strips) plus the first strip and the last one or two
+    // strips (>= MAX_FUSE columns) over the rows in between, in chunks of hf rows: thin tiles,
+    // one short round of wavefronts, so the faces are ready ~15 us into the pass.
+    int hf = 12;  // >= the deepest face (8-row bands were measured slower: more, even thinner tiles)
+    hf += (6 - (hf + 2 * (T - 1)) % 6) % 6;
+    const int nright = (nx - (nstrips - 1) * STRIDE >= MAX_FUSE) ? 1 : 2;
+    const bool split = ny >= 2 * hf + 1 && nstrips >= nright + 2;
+    Tiling tl{};
+    auto add = [&](int strip0, int nstrip, int j0, int j1, int rows) {
+        if (nstrip <= 0 || j1 < j0) return;
+        TileRegion& r = tl.r[tl.nregions++];
+        r.strip0 = strip0, r.nstrip = nstrip, r.j0 = j0, r.j1 = j1, r.ry = rows;
+        tl.ntiles += nstrip * cdiv(j1 - j0 + 1, rows);
+        r.t_end = tl.ntiles;
+    };
+    // rows j0..j1 of `nstrip` strips: full-height chunks, or — on launches of two or more rounds of wavefronts —
+    // a main region of 7/8 of the chunks (a multiple of four, so that its tiles fill whole blocks whatever the
+    // number of strips) followed by a tail region at half the height; returns the tail tiles
+    auto add_rows = [&](int strip0, int nstrip, int j0, int j1, int rows) -> int {
+        const int nrows = j1 - j0 + 1;
+        if (nstrip <= 0 || nrows <= 0) return 0;
+        const int nchunks = cdiv(nrows, rows);
+        if (!cfg.tail_split || rows < 48 || nchunks < 16 || static_cast<long>(nstrip) * nchunks < 8192) {
+            add(strip0, nstrip, j0, j1, rows);
+            return 0;
+        }
+        auto snap = [&](int r) { return r + (6 - (r + 2 * (T - 1)) % 6) % 6; };
+        const bool two_level = cfg.tail_split != 2;  // default: 7/8 of the chunks full height + the rest at half height;
+                                                     // 2 (experiment): 3/4 + half + quarter height — measured no better
+        const int main_chunks = (nchunks * (two_level ? 7 : 3) / (two_level ? 8 : 4)) / 4 * 4;
+        const int j_main = j0 + main_chunks * rows - 1;
+        const int half = snap(rows / 2), quarter = snap(rows / 4);
+        const int rest = j1 - j_main;                       // rows left for the tail regions
+        const int j_half = two_level ? j1 : j_main + (rest * 2 / 3) / half * half;  // about two thirds of them at half height
+        add(strip0, nstrip, j0, j_main, rows);
+        const int before = tl.ntiles;
+        add(strip0, nstrip, j_main + 1, j_half, half);
+        add(strip0, nstrip, j_half + 1, j1, quarter);
+        return tl.ntiles - before;
+    };
+    int tail_tiles = 0;
+    if (part == 0 || ((part == 1 || part == 3) && !split)) {
+        tail_tiles = add_rows(0, nstrips, 1, ny, ry);
+    } else if (part == 1 || part == 3) {
+        add(0, nstrips, 1, hf, hf);
+        add(0, nstrips, ny - hf + 1, ny, hf);
+        add(0, 1, hf + 1, ny - hf, hf);
+        add(nstrips - nright, nright, hf + 1, ny - hf, hf);
+    }
+    int nblocks;
+    if (part == 3 && split) {  // merged launch: the frame tiles above, then the bulk in the same grid
+        tl.frame_tiles = tl.ntiles;
+        tl.frame_blocks = cdiv(tl.ntiles, 4);
+        fs.nframe = static_cast<unsigned>(tl.frame_tiles);
+        const int before = tl.ntiles;
+        tail_tiles = add_rows(1, nstrips - 1 - nright, hf + 1, ny - hf, std::min(ry, ny - 2 * hf));
+        nblocks = tl.frame_blocks + cdiv(tl.ntiles - before, 4);
+    } else if (part == 3) {  // a tile that is all frame: every tile counts for the flag
+        tl.frame_tiles = tl.ntiles;
+        tl.frame_blocks = cdiv(tl.ntiles, 4);
+        tl.tail_blocks = 0;
+        tail_tiles = 0;
+        fs.nframe = static_cast<unsigned>(tl.frame_tiles);
+        nblocks = tl.frame_blocks;
+    } else {
+        if (part == 2 && split) tail_tiles = add_rows(1, nstrips - 1 - nright, hf + 1, ny - hf, std::min(ry, ny - 2 * hf));
+        if (tl.ntiles == 0) return hipSuccess;  // part 2 of a field that is all frame
+        nblocks = cdiv(tl.ntiles, 4);
+        fs = FrameSync{};
+    }
+    tl.tail_blocks = cdiv(tail_tiles, 4);
+    const dim3 grid(nblocks), block(256);
+    const int sw = cfg.xcd_swizzle;
+    const int sign = (p.vx >= 0.0 ? 2 : 0) + (p.vy >= 0.0 ? 1 : 0);
+#define CSIM_LAUNCH_O(SXV, SYV)                                                                        \
+    hipLaunchKernelGGL((k_sweepO_dpp<DIV, T, SXV, SYV>), grid, block, cfg.lds_bytes, st, in, out, nx, ny, pitch, \
+                       nstrips, tl, sw, p, bc, fin, fs)
+    if (DIV == 3) {  // coefficient form: the upwind directions are folded into the coefficients
+        CSIM_LAUNCH_O(1, 1);
+    } else {
+        switch (sign) {
+            case 3: CSIM_LAUNCH_O(1, 1); break;
+            case 2: CSIM_LAUNCH_O(1, 0); break;
+            case 1: CSIM_LAUNCH_O(0, 1); break;
+            default: CSIM_LAUNCH_O(0, 0); break;
+        }
+    }
+#undef CSIM_LAUNCH_O
+    return hipGetLastError();
+}
+
+template <int T>
+hipError_t sweepO_T(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
+                           const SweepCfg& cfg, const Bc2& bc, const FinLines& fin, int part, hipStream_t st,
+                           const FrameSync& fs) {
+    switch (p.div_mode) {
+        case 0: return sweepO_div<0, T>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st, fs);
+        case 1: return sweepO_div<1, T>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st, fs);
+        case 3: return sweepO_div<3, T>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st, fs);
+        default: return sweepO_div<2, T>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st, fs);
+    }
+}
+
+
+// Split build (csrc/Makefile, -DCSIM_SPLIT_BUILD): the six instantiations sweepO_T<2..7> — 60 kernels with two
+// bodies each, 90 % of this file's compile time — are built as six translation units in parallel
+// (-DCSIM_INST_T=N: this file up to here plus one explicit instantiation) next to the main one, which only
+// declares them.  Without the macros (tools that include this file) everything is instantiated here.
+#ifdef CSIM_INST_T
+template hipError_t sweepO_T<CSIM_INST_T>(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
+                                    const SweepCfg& cfg, const Bc2& bc, const FinLines& fin, int part, hipStream_t st,
+                                    const FrameSync& fs);
+#elif defined(CSIM_SPLIT_BUILD)
+extern template hipError_t sweepO_T<2>(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
+                                    const SweepCfg& cfg, const Bc2& bc, const FinLines& fin, int part, hipStream_t st,
+                                    const FrameSync& fs);
+extern template hipError_t sweepO_T<3>(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
+                                    const SweepCfg& cfg, const Bc2& bc, const FinLines& fin, int part, hipStream_t st,
+                                    const FrameSync& fs);
+extern template hipError_t sweepO_T<4>(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
+                                    const SweepCfg& cfg, const Bc2& bc, const FinLines& fin, int part, hipStream_t st,
+                                    const FrameSync& fs);
+extern template hipError_t sweepO_T<5>(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
+                                    const SweepCfg& cfg, const Bc2& bc, const FinLines& fin, int part, hipStream_t st,
+                                    const FrameSync& fs);
+extern template hipError_t sweepO_T<6>(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
+                                    const SweepCfg& cfg, const Bc2& bc, const FinLines& fin, int part, hipStream_t st,
+                                    const FrameSync& fs);
+extern template hipError_t sweepO_T<7>(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
+                                    const SweepCfg& cfg, const Bc2& bc, const FinLines& fin, int part, hipStream_t st,
+                                    const FrameSync& fs);
+#endif
+
+#ifndef CSIM_INST_T  // ---- everything below lives in the main translation unit only ----------------------
+
 // -------------------------------------------------------------------------------------------
 // VAR_LDS — LDS-staged marching sweep.  A 256-thread workgroup owns a 512-column strip; every
 // row is loaded once (16 B per lane), staged in a double-buffered LDS row (ds_write_b128) with
@@ -1002,7 +1167,6 @@ __global__ __launch_bounds__(256) void k_reduce(const double* __restrict__ a,
 // ============================================================================================
 // launchers
 // ============================================================================================
-static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 template <int DIV>
 static hipError_t sweep_div(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
@@ -1036,134 +1200,6 @@ static hipError_t sweep_div(const double* in, double* out, int nx, int ny, int p
                                ry, nwgx, cfg.xcd_swizzle, p);
     }
     return hipGetLastError();
-}
-
-template <int DIV, int T>
-static hipError_t sweepO_div(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
-                             const SweepCfg& cfg, const Bc2& bc, const FinLines& fin, int part, hipStream_t st,
-                             FrameSync fs) {
-    constexpr int STRIDE = OverlapGeom<T>::STRIDE;
-    const int nstrips = cdiv(nx, STRIDE);
-    int ry = cfg.rows_per_chunk;
-    if (ry <= 0) {
-        if (cfg.tuned_rows > 0) {
-            ry = cfg.tuned_rows;
-        } else {
-            ry = 64;
-            while (ry > 16 && static_cast<long>(nstrips) * cdiv(ny, ry) < 8192) ry >>= 1;
-            // tiles too small for the on-device trial (< 4 M cells): a launch is at most a round or two of
-            // wavefronts and the length of a wavefront's march decides — the shortest chunks win although
-            // they double the overhead rows (512^2: +52 %, 1024^2: +37 %, 2048^2: +25 % against 18 rows)
-            if (static_cast<long>(nx) * ny < (1L << 22)) ry = 6;
-        }
-        // the march runs whole groups of six iterations: make ry + 2 (T - 1) a multiple of six so
-        // that only a ragged last chunk computes surplus rows
-        ry += (6 - (ry + 2 * (T - 1)) % 6) % 6;
-    }
-    if (ry > ny) ry = ny;
-    if (cfg.rows_used && part != 1) *cfg.rows_used = ry;
-    // part 0: the whole field.  part 1 / 2 (multi-rank pass): FRAME / BULK.  The frame is the
-    // bottom and top bands (hf rows, all strips) plus the first strip and the last one or two
-    // strips (>= MAX_FUSE columns) over the rows in between, in chunks of hf rows: thin tiles,
-    // one short round of wavefronts, so the faces are ready ~15 us into the pass.
-    int hf = 12;  // >= the deepest face (8-row bands were measured slower: more, even thinner tiles)
-    hf += (6 - (hf + 2 * (T - 1)) % 6) % 6;
-    const int nright = (nx - (nstrips - 1) * STRIDE >= MAX_FUSE) ? 1 : 2;
-    const bool split = ny >= 2 * hf + 1 && nstrips >= nright + 2;
-    Tiling tl{};
-    auto add = [&](int strip0, int nstrip, int j0, int j1, int rows) {
-        if (nstrip <= 0 || j1 < j0) return;
-        TileRegion& r = tl.r[tl.nregions++];
-        r.strip0 = strip0, r.nstrip = nstrip, r.j0 = j0, r.j1 = j1, r.ry = rows;
-        tl.ntiles += nstrip * cdiv(j1 - j0 + 1, rows);
-        r.t_end = tl.ntiles;
-    };
-    // rows j0..j1 of `nstrip` strips: full-height chunks, or — on launches of two or more rounds of wavefronts —
-    // a main region of 7/8 of the chunks (a multiple of four, so that its tiles fill whole blocks whatever the
-    // number of strips) followed by a tail region at half the height; returns the tail tiles
-    auto add_rows = [&](int strip0, int nstrip, int j0, int j1, int rows) -> int {
-        const int nrows = j1 - j0 + 1;
-        if (nstrip <= 0 || nrows <= 0) return 0;
-        const int nchunks = cdiv(nrows, rows);
-        if (!cfg.tail_split || rows < 48 || nchunks < 16 || static_cast<long>(nstrip) * nchunks < 8192) {
-            add(strip0, nstrip, j0, j1, rows);
-            return 0;
-        }
-        auto snap = [&](int r) { return r + (6 - (r + 2 * (T - 1)) % 6) % 6; };
-        const bool two_level = cfg.tail_split != 2;  // default: 7/8 of the chunks full height + the rest at half height;
-                                                     // 2 (experiment): 3/4 + half + quarter height — measured no better
-        const int main_chunks = (nchunks * (two_level ? 7 : 3) / (two_level ? 8 : 4)) / 4 * 4;
-        const int j_main = j0 + main_chunks * rows - 1;
-        const int half = snap(rows / 2), quarter = snap(rows / 4);
-        const int rest = j1 - j_main;                       // rows left for the tail regions
-        const int j_half = two_level ? j1 : j_main + (rest * 2 / 3) / half * half;  // about two thirds of them at half height
-        add(strip0, nstrip, j0, j_main, rows);
-        const int before = tl.ntiles;
-        add(strip0, nstrip, j_main + 1, j_half, half);
-        add(strip0, nstrip, j_half + 1, j1, quarter);
-        return tl.ntiles - before;
-    };
-    int tail_tiles = 0;
-    if (part == 0 || ((part == 1 || part == 3) && !split)) {
-        tail_tiles = add_rows(0, nstrips, 1, ny, ry);
-    } else if (part == 1 || part == 3) {
-        add(0, nstrips, 1, hf, hf);
-        add(0, nstrips, ny - hf + 1, ny, hf);
-        add(0, 1, hf + 1, ny - hf, hf);
-        add(nstrips - nright, nright, hf + 1, ny - hf, hf);
-    }
-    int nblocks;
-    if (part == 3 && split) {  // merged launch: the frame tiles above, then the bulk in the same grid
-        tl.frame_tiles = tl.ntiles;
-        tl.frame_blocks = cdiv(tl.ntiles, 4);
-        fs.nframe = static_cast<unsigned>(tl.frame_tiles);
-        const int before = tl.ntiles;
-        tail_tiles = add_rows(1, nstrips - 1 - nright, hf + 1, ny - hf, std::min(ry, ny - 2 * hf));
-        nblocks = tl.frame_blocks + cdiv(tl.ntiles - before, 4);
-    } else if (part == 3) {  // a tile that is all frame: every tile counts for the flag
-        tl.frame_tiles = tl.ntiles;
-        tl.frame_blocks = cdiv(tl.ntiles, 4);
-        tl.tail_blocks = 0;
-        tail_tiles = 0;
-        fs.nframe = static_cast<unsigned>(tl.frame_tiles);
-        nblocks = tl.frame_blocks;
-    } else {
-        if (part == 2 && split) tail_tiles = add_rows(1, nstrips - 1 - nright, hf + 1, ny - hf, std::min(ry, ny - 2 * hf));
-        if (tl.ntiles == 0) return hipSuccess;  // part 2 of a field that is all frame
-        nblocks = cdiv(tl.ntiles, 4);
-        fs = FrameSync{};
-    }
-    tl.tail_blocks = cdiv(tail_tiles, 4);
-    const dim3 grid(nblocks), block(256);
-    const int sw = cfg.xcd_swizzle;
-    const int sign = (p.vx >= 0.0 ? 2 : 0) + (p.vy >= 0.0 ? 1 : 0);
-#define CSIM_LAUNCH_O(SXV, SYV)                                                                        \
-    hipLaunchKernelGGL((k_sweepO_dpp<DIV, T, SXV, SYV>), grid, block, cfg.lds_bytes, st, in, out, nx, ny, pitch, \
-                       nstrips, tl, sw, p, bc, fin, fs)
-    if (DIV == 3) {  // coefficient form: the upwind directions are folded into the coefficients
-        CSIM_LAUNCH_O(1, 1);
-    } else {
-        switch (sign) {
-            case 3: CSIM_LAUNCH_O(1, 1); break;
-            case 2: CSIM_LAUNCH_O(1, 0); break;
-            case 1: CSIM_LAUNCH_O(0, 1); break;
-            default: CSIM_LAUNCH_O(0, 0); break;
-        }
-    }
-#undef CSIM_LAUNCH_O
-    return hipGetLastError();
-}
-
-template <int T>
-static hipError_t sweepO_T(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
-                           const SweepCfg& cfg, const Bc2& bc, const FinLines& fin, int part, hipStream_t st,
-                           const FrameSync& fs) {
-    switch (p.div_mode) {
-        case 0: return sweepO_div<0, T>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st, fs);
-        case 1: return sweepO_div<1, T>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st, fs);
-        case 3: return sweepO_div<3, T>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st, fs);
-        default: return sweepO_div<2, T>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st, fs);
-    }
 }
 
 // overlapped-strip multi-step sweep, T = 2..7 (kind[] / part: see internal.hpp)
@@ -1312,5 +1348,7 @@ hipError_t launch_linf(const double* a, const double* b, int nx, int ny, int pit
                        scratch);
     return hipGetLastError();
 }
+
+#endif  // !CSIM_INST_T
 
 }  // namespace csim
