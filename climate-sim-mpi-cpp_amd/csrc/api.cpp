@@ -517,7 +517,11 @@ int csim_stepper_create(const csim_decomp* dec, double dx, double dy, const int 
         const int px = dec->dims[0] > 0 ? dec->dims[0] : 1, py = dec->dims[1] > 0 ? dec->dims[1] : 1;
         const int gx = dec->nx_global > 0 ? dec->nx_global : s->nx, gy = dec->ny_global > 0 ? dec->ny_global : s->ny;
         const int bx = gx / px, by = gy / py;
-        s->tile_cells = static_cast<long>(s->multi ? bx : s->nx) * (s->multi ? by : s->ny);
+        // the size classes of the pass planner are single-rank measurements; across ranks every pass carries an
+        // exchange whose cost does not shrink with the depth, so shallow passes lose what they gain (20-step
+        // runs on the 4096 x 8192 self-torus: 4 x 5 932 k, 7 + 7 + 6 1 176 k): multi-rank steppers plan with the
+        // mid-size table (preferred depth 6, depth 7 where it saves a pass)
+        s->tile_cells = s->multi ? 0 : static_cast<long>(s->nx) * s->ny;
         const int min_tile = s->multi ? std::min(bx, by) : MAX_FUSE;
         s->fuse_cap = std::max(1, std::min(MAX_FUSE, min_tile));
     }
@@ -1220,10 +1224,17 @@ static int fused_depth(const csim_stepper* s) {
 // two or more steps never contains a single-step pass unless it must (tiles only two cells deep and an odd
 // K): one step alone costs 4.5 steps of a deep pass, so the programme avoids it by itself.  The result
 // depends on (K, cap) only, so every rank of a decomposition derives the same schedule.
-static const double STEP_COST[MAX_FUSE + 1] = {0.0, 4.52, 2.32, 1.55, 1.206, 1.09, 1.0, 1.06};
-static const double STEP_COST_BIG[MAX_FUSE + 1] = {0.0, 4.52, 2.32, 1.55, 1.24, 1.09, 1.0, 0.991};  // tiles >= BIG_TILE_CELLS
-static const double STEP_COST_SMALL[MAX_FUSE + 1] = {0.0, 3.0, 1.5, 1.03, 1.0, 1.0, 1.2, 1.22};    // tiles < SMALL_TILE_CELLS (relative to T = 4)
-static const double PASS_COST = 0.05;
+// (tools/depth_ab.py, profiles/r02_depth_ab.jsonl; relative to the preferred depth of the size class)
+static const double STEP_COST_BIG[MAX_FUSE + 1] = {0.0, 4.52, 2.32, 1.55, 1.24, 1.09, 1.0, 0.991};    // >= 2e8 cells (16384^2, 32768^2)
+static const double STEP_COST_MID[MAX_FUSE + 1] = {0.0, 4.52, 2.32, 1.55, 1.20, 1.04, 1.0, 1.005};    // 5e7 .. 2e8 (8192^2, 8192 x 16384)
+static const double STEP_COST_MIDSMALL[MAX_FUSE + 1] = {0.0, 4.0, 2.0, 1.40, 1.12, 1.0, 1.0, 1.10};   // 1.2e7 .. 5e7 (4096^2, 4096 x 8192)
+static const double STEP_COST_SMALL[MAX_FUSE + 1] = {0.0, 3.0, 1.5, 1.03, 1.0, 1.0, 1.2, 1.22};       // < 1.2e7 (relative to T = 4)
+static const double* step_cost_table(long tile_cells) {
+    if (tile_cells >= BIG_TILE_CELLS) return STEP_COST_BIG;
+    if (tile_cells <= 0 || tile_cells >= 50000000L) return STEP_COST_MID;  // (0 = size unknown)
+    return tile_cells >= SMALL_TILE_CELLS ? STEP_COST_MIDSMALL : STEP_COST_SMALL;
+}
+static const double PASS_COST = 0.1;   // launch and inter-kernel gap, in time steps of the preferred depth
 static const long SHORT_RUN_PASSES = 16;  // overlap 5: runs of fewer passes go bulk-first (see pass_fused_bulk_first)
 // The plan is `lead` passes of depth `lead_depth` followed by the passes listed in `tail` (a run of 10^9
 // steps must not materialise 10^8 entries).
@@ -1235,8 +1246,7 @@ struct PassPlan {
     int at(long k) const { return k < lead ? lead_depth : tail[static_cast<size_t>(k - lead)]; }
 };
 static void plan_passes(int K, int cap, bool balanced, long tile_cells, PassPlan& plan) {
-    const double* step_cost = tile_cells >= BIG_TILE_CELLS ? STEP_COST_BIG
-                              : (tile_cells > 0 && tile_cells < SMALL_TILE_CELLS) ? STEP_COST_SMALL : STEP_COST;
+    const double* step_cost = step_cost_table(tile_cells);
     plan = PassPlan{};
     std::vector<int>& out = plan.tail;
     if (K <= 0) return;

@@ -166,9 +166,9 @@ int csim_stepper_exchange_halos(csim_stepper* s);
 int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy, int nsteps);
 /* The pass schedule of csim_stepper_run(nsteps) as pure host arithmetic: depths[k] = time steps the k-th
  * HBM pass advances (the first max_depths of *npasses entries).  smallest_tile = min over the decomposition
- * of the local nx, ny (the face depth cannot exceed it; MAX for one rank), tile_cells = cells of the
- * decomposition's base tile (nx_global / dims[0]) x (ny_global / dims[1]) (tiles of >= 2e8 cells prefer depth 7,
- * smaller ones 6), fuse = the option "fuse".  It depends on these numbers only, so every rank derives the same
+ * of the local nx, ny (the face depth cannot exceed it; MAX for one rank), tile_cells = nx * ny of a single-rank
+ * stepper (>= 2e8 cells prefer depth 7, below 1.2e7 depth 4, else 6) and 0 for a multi-rank one (every pass
+ * carries an exchange: depth 6, or 7 where it saves a pass), fuse = the option "fuse".  It depends on these numbers only, so every rank derives the same
  * schedule without communicating. */
 int csim_pass_schedule(int nsteps, int smallest_tile, long tile_cells, int fuse, int* depths, int max_depths,
                        long* npasses);
