@@ -141,6 +141,35 @@ def test_torus_mixed_physical_and_linked_sides_depth6(csim, sides, bc, overlap):
     assert np.array_equal(got[mask], want[mask]), float(np.abs(got - want)[mask].max())
 
 
+def test_torus_on_an_8192_square_tile_bulk_with_tail_region(csim):
+    """the 4-GPU tile: its bulk is more than two rounds of wavefronts, so the merged and the bulk-first launches
+    carry a TAIL region of half-height chunks behind the XCD-remapped main tiles (Tiling::tail_blocks) — the
+    block -> tile map of a three-part grid (frame, main, tail).  Every schedule must leave the field the serial
+    single-step schedule leaves (which the smaller torus tests tie to the oracle), bit for bit."""
+    n, steps = 8192, 19
+    D, vx, vy, dt = 0.05, 0.5, -0.25, 0.1
+    d = self_neighbor_decomp(csim, n, n, (1, 1, 1, 1))
+    ref = None
+    for opts in [dict(overlap=0, fuse=0), dict(overlap=3, fuse=6), dict(overlap=4, fuse=7), dict(overlap=5, fuse=-1),
+                 dict(overlap=3, fuse=6, tail_split=0), dict(overlap=1, fuse=5, rows_per_chunk=50)]:
+        st = csim.Stepper(d, 1.0, 1.0, csim.bc_codes("dddd"))
+        st.comm_init(csim.comm_unique_id())
+        for k, v in opts.items():
+            st.set_option(k, v)
+        st.init_gaussian(1.0, 0.02, 0.97, 0.03)   # hotspot on a torus corner: all 8 faces carry data
+        mass0 = st.sum()
+        st.run(D, dt, vx, vy, steps)
+        out = st.download_interior()
+        mass1 = st.sum()
+        st.close()
+        assert abs(mass1 - mass0) <= 1e-12 * abs(mass0)   # a torus loses nothing
+        if ref is None:
+            ref = out
+            assert ref[0, 0] > 0 and ref[-1, -1] > 0 and ref[0, -1] > 0 and ref[-1, 0] > 0
+        else:
+            assert np.array_equal(out, ref), opts
+
+
 def test_exchange_halos_alone(csim):
     """reference tests/simulation/unit/test_halo.cpp:36-56 restated: after exchange_halos every
     ghost face on a neighbour side holds the neighbour's edge cells, physical sides untouched."""
