@@ -170,6 +170,42 @@ def test_torus_on_an_8192_square_tile_bulk_with_tail_region(csim):
             assert np.array_equal(out, ref), opts
 
 
+def test_fuzz_random_torus_cases_vs_oracle(csim):
+    """120 seeded random cases of the RCCL path on the self-linked torus: tile shape, which side pairs are linked,
+    the BC of the physical sides, physics, step count cut into two run() calls, pass depth, exchange schedule —
+    the full array (ghost ring included, corners excepted: SURVEY Q7) against the oracle's torus."""
+    rng = np.random.default_rng(777)
+    for case in range(120):
+        nx, ny = int(rng.integers(8, 700)), int(rng.integers(8, 260))
+        sides = [(1, 1, 1, 1), (1, 1, 0, 0), (0, 0, 1, 1)][int(rng.integers(0, 3))]
+        bc = "".join(rng.choice(list("dnp"), 4))
+        D = float(rng.choice([0.0, 0.05, 0.2]))
+        vx, vy = float(rng.choice([0.5, -0.5, 0.0])), float(rng.choice([0.25, -0.25, 0.0]))
+        dt = 0.1 if (D or vx or vy) else 0.1
+        steps = int(rng.integers(2, 26))
+        opts = dict(overlap=int(rng.choice([0, 1, 3, 4, 5])), fuse=int(rng.choice([-1, -1, 0, 2, 3, 4, 5, 6, 7])),
+                    rows_per_chunk=int(rng.choice([0, 0, 3, 20])))
+        u0 = np.zeros((ny + 2, nx + 2))
+        u0[1:-1, 1:-1] = rng.standard_normal((ny, nx))
+        u0[0, :], u0[-1, :], u0[:, 0], u0[:, -1] = rng.standard_normal(4)
+        codes = csim.bc_codes(bc)
+        want = torus_oracle(u0, 1.0, 1.0, D, vx, vy, dt, steps, sides, codes)
+        st = csim.Stepper(self_neighbor_decomp(csim, nx, ny, sides), 1.0, 1.0, codes)
+        st.comm_init(csim.comm_unique_id())
+        for k, v in opts.items():
+            st.set_option(k, v)
+        st.upload(u0)
+        a = int(rng.integers(1, steps))
+        st.run(D, dt, vx, vy, a)
+        st.run(D, dt, vx, vy, steps - a)
+        got = st.download()
+        st.close()
+        mask = np.ones(got.shape, bool)
+        mask[[0, 0, -1, -1], [0, -1, 0, -1]] = False
+        assert np.array_equal(got[mask], want[mask]), (case, nx, ny, sides, bc, D, vx, vy, steps, a, opts,
+                                                       float(np.abs(got - want)[mask].max()))
+
+
 def test_exchange_halos_alone(csim):
     """reference tests/simulation/unit/test_halo.cpp:36-56 restated: after exchange_halos every
     ghost face on a neighbour side holds the neighbour's edge cells, physical sides untouched."""
