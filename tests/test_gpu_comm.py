@@ -171,11 +171,11 @@ def test_torus_on_an_8192_square_tile_bulk_with_tail_region(csim):
 
 
 def test_fuzz_random_torus_cases_vs_oracle(csim):
-    """120 seeded random cases of the RCCL path on the self-linked torus: tile shape, which side pairs are linked,
+    """80 seeded random cases of the RCCL path on the self-linked torus: tile shape, which side pairs are linked,
     the BC of the physical sides, physics, step count cut into two run() calls, pass depth, exchange schedule —
     the full array (ghost ring included, corners excepted: SURVEY Q7) against the oracle's torus."""
     rng = np.random.default_rng(777)
-    for case in range(120):
+    for case in range(80):
         nx, ny = int(rng.integers(8, 700)), int(rng.integers(8, 260))
         sides = [(1, 1, 1, 1), (1, 1, 0, 0), (0, 0, 1, 1)][int(rng.integers(0, 3))]
         bc = "".join(rng.choice(list("dnp"), 4))
