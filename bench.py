@@ -497,7 +497,9 @@ def main():
             "step_equivalent_x_peak": step_eq_bytes / secs / 1e9 / HBM_PEAK_GBS,
             "note": "frac = PMC traffic / live kernel time / 8 TB/s.  step_equivalent_* counts 16 B per cell-UPDATE "
                     "(SURVEY §8d) and exceeds the peak because T time levels stay in registers per pass; it is "
-                    "the figure to compare with a one-step-per-pass sweep, not a bandwidth",
+                    "the figure to compare with a one-step-per-pass sweep, not a bandwidth.  A deeper pass LOWERS frac while "
+                    "raising the throughput (16384^2: T = 6 0.54, T = 7 0.46 at +0.9 % Mcell-updates/s): the kernel is bound "
+                    "by fp64 VALU issue (roofline_valu: VALUs ~96 % busy at the clock the chip holds), not by HBM",
         }
         ops_per_update = FP64_OPS_PER_UPDATE if not args.contract else 5
         useful_tops = local_cells * T * ops_per_update / secs / 1e12
