@@ -154,6 +154,7 @@ struct csim_stepper {
     unsigned long long* frame_flag = nullptr;
     unsigned long long pass_no = 0;
     int frame_fence = 0, frame_prio = 1;  // experiment switches of mode 3, see FrameSync
+    int direct_faces = 1;                 // merged launch: the frame wavefronts fill send2[] themselves (no pack kernel)
     bool bulk_first_run = false;          // the current csim_stepper_run uses pass_fused_bulk_first
     // asynchronous snapshot of the interior (device staging copy + pinned host buffer + I/O stream)
     double* snap_d = nullptr;
@@ -1072,6 +1073,7 @@ static int pass_fused(csim_stepper* s, const Phys& p, int T, int next_T, bool fi
     int rc = prof_begin(s, T);
     if (rc) return rc;
     if (rccl && s->overlap && next_T >= 2) {
+        bool direct = false;
         if ((s->overlap == 3 || s->overlap == 5) && s->frame_flag) {
             // ONE launch: the frame tiles are the first blocks of the grid, the bulk tiles fill the rest of
             // the chip at once; the last frame wavefront publishes this pass's number and the comm stream,
@@ -1082,6 +1084,11 @@ static int pass_fused(csim_stepper* s, const Phys& p, int T, int next_T, bool fi
             fs.pass = ++s->pass_no;
             fs.fence = s->frame_fence;
             fs.prio = s->frame_prio;
+            direct = s->direct_faces && s->frame_fence == 0;
+            if (direct) {  // the frame wavefronts write the next pass's faces into send2[] before they count themselves
+                for (int d = 0; d < 8; ++d) fs.face[d] = s->send2[d];
+                fs.face_depth = next_T;
+            }
             CSIM_HIP(launch_fused(s, p, kind, T, 3, s->s_comp, false, 0, &fs));
             CSIM_HIP(hipStreamWaitValue64(s->s_comm, s->frame_flag, fs.pass, hipStreamWaitValueGte, ~0ull));
         } else {
@@ -1095,7 +1102,7 @@ static int pass_fused(csim_stepper* s, const Phys& p, int T, int next_T, bool fi
         long comm_slot = -1;
         rc = prof_start(s, csim_stepper::PROF_COMM, s->s_comm, &comm_slot);
         if (rc) return rc;
-        CSIM_HIP(launch_halo2_pack(s->nxt, s->nx, s->ny, s->pitch, next_T, s->send2, s->s_comm));
+        if (!direct) CSIM_HIP(launch_halo2_pack(s->nxt, s->nx, s->ny, s->pitch, next_T, s->send2, s->s_comm));
         rc = post_exchange2(s, next_T, s->s_comm);
         if (rc) return rc;
         if (s->overlap == 1 || s->overlap == 3 || s->overlap == 5) {
@@ -1419,6 +1426,8 @@ int csim_stepper_set_option(csim_stepper* s, const char* key, long value) {
         s->frame_fence = static_cast<int>(value);
     } else if (k == "frame_prio") {
         s->frame_prio = value != 0;
+    } else if (k == "direct_faces") {
+        s->direct_faces = value != 0;
     } else if (k == "external_halo") {
         s->external = value != 0;
         s->halo_fresh = false;
@@ -1462,6 +1471,7 @@ int csim_stepper_get_option(const csim_stepper* s, const char* key, long* value)
     else if (k == "xcd_swizzle") *value = s->cfg.xcd_swizzle;
     else if (k == "tail_split") *value = s->cfg.tail_split;
     else if (k == "overlap") *value = s->overlap;
+    else if (k == "direct_faces") *value = s->direct_faces;
     else if (k == "external_halo") *value = s->external;
     else if (k == "fuse") *value = s->fuse;
     else if (k == "contract") *value = s->contract;

@@ -91,6 +91,10 @@ struct FrameSync {
     int fence = 0;        // 0 write-through result stores + drain (default), 1 plain stores + agent-scope fence per
                           // wavefront (slow), 2 plain stores, drain only (timing experiments: NOT safe)
     int prio = 1;         // frame wavefronts raise their issue priority
+    // direct faces (face_depth > 0): the frame wavefronts also copy the cells that form the faces of the NEXT pass
+    // (depth face_depth, k_halo2_pack's layout) straight into the send buffers; nullptr = no peer in that direction
+    double* face[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int face_depth = 0;
 };
 hipError_t launch_sweepO(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
                          const SweepCfg& cfg, const int kind[4], double value, int T, int part,

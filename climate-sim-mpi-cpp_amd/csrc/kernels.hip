@@ -135,6 +135,29 @@ __device__ __forceinline__ void store_pair_wt(double* dst, double ox, double oy,
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Direct faces (merged launch): one cell (column i in 0..nx+1, row j in 0..ny+1; 0 and n+1 = ghost lines) of the
+// field a frame tile has just written goes into every face of the NEXT pass it belongs to.  Indexing is
+// k_halo2_pack's for depth H: column faces [c][j] over rows 0..ny+1, row faces [r][i] over columns 0..nx+1 (the
+// ghost entries travel along: Periodic ghosts are never rewritten), corner blocks [r][c] of interior cells.
+__device__ __forceinline__ void face_store_cell(const FrameSync& fs, int i, int j, double v, int nx, int ny) {
+    const int H = fs.face_depth;
+    const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(v));
+    auto put = [&](double* face, int idx) {  // write-through, like the tile's own result stores
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(face + idx), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    const bool in_i = i >= 1 && i <= nx, in_j = j >= 1 && j <= ny;
+    const bool l = in_i && i <= H, r = in_i && i >= nx - H + 1, b = in_j && j <= H, t = in_j && j >= ny - H + 1;
+    const int cl = i - 1, cr = i - (nx - H + 1), rb = j - 1, rt = j - (ny - H + 1);
+    if (l && fs.face[0]) put(fs.face[0], cl * (ny + 2) + j);
+    if (r && fs.face[1]) put(fs.face[1], cr * (ny + 2) + j);
+    if (b && fs.face[2]) put(fs.face[2], rb * (nx + 2) + i);
+    if (t && fs.face[3]) put(fs.face[3], rt * (nx + 2) + i);
+    if (l && b && fs.face[4]) put(fs.face[4], rb * H + cl);
+    if (r && b && fs.face[5]) put(fs.face[5], rb * H + cr);
+    if (l && t && fs.face[6]) put(fs.face[6], rt * H + cl);
+    if (r && t && fs.face[7]) put(fs.face[7], rt * H + cr);
+}
+
 __device__ __forceinline__ void store_pair(double* dst, double ox, double oy, int nvalid) {
     if (nvalid >= 2) {
         *reinterpret_cast<double2*>(dst) = make_double2(ox, oy);
@@ -537,6 +560,37 @@ __global__ __launch_bounds__(256) void k_sweepO_dpp(const double* __restrict__ i
         // the waiting side reads it through the command processor).
         if (fs.fence == 0)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (fs.fence == 0 && fs.face_depth > 0) {
+            // Direct faces: this wavefront copies the part of its tile that belongs to a face of the NEXT pass
+            // (and the ghost entries beside it) into the send buffers, so the comm stream can post the RCCL
+            // group at the flag without a pack kernel in between.  Done after the march by reading the tile
+            // back (its stores are drained and written through; the loads bypass the vector L1): the same
+            // stores inside the march loop cost 20 more VGPRs, i.e. one wavefront per SIMD.
+            const int H = fs.face_depth;
+            const int gx = g0 + 2 * lane;
+            const bool out_lane = 2 * lane >= TP && 2 * lane < TP + STRIDE && gx < nx;
+            const bool rows_near = jb <= H || je >= ny - H + 1;              // wave-uniform
+            const bool cols_near = g0 + TP < H || g0 + TP + STRIDE > nx - H;  // wave-uniform
+            if (rows_near || cols_near) {
+                const int j0 = jb == 1 ? 0 : jb, j1 = je == ny ? ny + 1 : je;
+                auto ldf = [&](const double* q) {
+                    return __longlong_as_double(static_cast<long long>(__hip_atomic_load(
+                        reinterpret_cast<const unsigned long long*>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+                };
+                for (int rho = j0; rho <= j1; ++rho) {
+                    if (!out_lane) continue;
+                    const double* src = out + static_cast<ptrdiff_t>(rho) * pitch + LPAD + gx;  // cell (gx + 1, rho)
+                    face_store_cell(fs, gx + 1, rho, ldf(src), nx, ny);
+                    if (gx + 1 < nx) face_store_cell(fs, gx + 2, rho, ldf(src + 1), nx, ny);
+                    if (gx == 0) face_store_cell(fs, 0, rho, ldf(src - 1), nx, ny);
+                    if (gx + 1 == nx) face_store_cell(fs, nx + 1, rho, ldf(src + 1), nx, ny);
+                    if (gx + 2 == nx) face_store_cell(fs, nx + 1, rho, ldf(src + 2), nx, ny);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        if (fs.fence == 0)
+            ;
         else if (fs.fence == 1)
             __threadfence();
         else

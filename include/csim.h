@@ -198,6 +198,9 @@ int csim_stepper_sum(csim_stepper* s, double* out);
  *                    without an event or a second launch (without signal memory: as 1); 4 bulk launch first with
  *                    THIS pass's exchange under it, then the frame launch — no pass of a run, not even the first,
  *                    waits for an unhidden exchange; 5 (default) = 4 on runs of fewer than 16 passes, 3 otherwise
+ *   "direct_faces"   0/1 (default 1), schedule 3: the frame wavefronts copy the cells that form the NEXT pass's faces
+ *                    straight into the RCCL send buffers before they publish the flag (0: a pack kernel on the
+ *                    comm stream does it after the flag)
  *   "external_halo"  0/1 the caller carries the faces (csim_stepper_halo_* / _faces_*)
  *   "profile"        0 off, k >= 1: HIP events around the sweep launch(es) of every k-th pass
  *                    (csim_stepper_kernel_time)

@@ -141,6 +141,38 @@ def test_torus_mixed_physical_and_linked_sides_depth6(csim, sides, bc, overlap):
     assert np.array_equal(got[mask], want[mask]), float(np.abs(got - want)[mask].max())
 
 
+@pytest.mark.parametrize("direct", [1, 0])
+@pytest.mark.parametrize("shape", [(1161, 301, 6), (897, 130, 7), (300, 171, 5), (2049, 64, 4), (127, 40, 3), (64, 515, 2)])
+@pytest.mark.parametrize("sides,bc", [((1, 1, 1, 1), "dddd"), ((1, 1, 0, 0), "ddpn"), ((0, 0, 1, 1), "pndd")])
+def test_merged_launch_direct_faces_vs_pack_kernel(csim, direct, shape, sides, bc):
+    """schedule 3 with the frame wavefronts writing the NEXT pass's faces straight into the RCCL send buffers
+    ("direct_faces" = 1, default) and with the pack kernel on the comm stream (0): odd and even widths (the lane
+    that owns column nx carries the right ghost entry), tiles of one strip and of many, every depth, Periodic
+    ghosts (which travel inside the faces) beside linked sides — the full array against the oracle's torus."""
+    nx, ny, depth = shape
+    steps = 3 * depth + 2
+    D, vx, vy, dt = 0.05, -0.5, 0.25, 0.1
+    rng = np.random.default_rng(nx + ny)
+    u0 = np.zeros((ny + 2, nx + 2))
+    u0[1:-1, 1:-1] = rng.standard_normal((ny, nx))
+    u0[0, :], u0[-1, :], u0[:, 0], u0[:, -1] = 0.5, -0.25, 0.125, -1.5
+    codes = csim.bc_codes(bc)
+    want = torus_oracle(u0, 1.0, 1.0, D, vx, vy, dt, steps, sides, codes)
+    st = csim.Stepper(self_neighbor_decomp(csim, nx, ny, sides), 1.0, 1.0, codes)
+    st.comm_init(csim.comm_unique_id())
+    st.set_option("overlap", 3)
+    st.set_option("fuse", depth)
+    st.set_option("direct_faces", direct)
+    assert st.get_option("direct_faces") == direct
+    st.upload(u0)
+    st.run(D, dt, vx, vy, steps)
+    got = st.download()
+    st.close()
+    mask = np.ones(got.shape, bool)
+    mask[[0, 0, -1, -1], [0, -1, 0, -1]] = False
+    assert np.array_equal(got[mask], want[mask]), float(np.abs(got - want)[mask].max())
+
+
 def test_torus_on_an_8192_square_tile_bulk_with_tail_region(csim):
     """the 4-GPU tile: its bulk is more than two rounds of wavefronts, so the merged and the bulk-first launches
     carry a TAIL region of half-height chunks behind the XCD-remapped main tiles (Tiling::tail_blocks) — the
@@ -151,7 +183,8 @@ def test_torus_on_an_8192_square_tile_bulk_with_tail_region(csim):
     d = self_neighbor_decomp(csim, n, n, (1, 1, 1, 1))
     ref = None
     for opts in [dict(overlap=0, fuse=0), dict(overlap=3, fuse=6), dict(overlap=4, fuse=7), dict(overlap=5, fuse=-1),
-                 dict(overlap=3, fuse=6, tail_split=0), dict(overlap=1, fuse=5, rows_per_chunk=50)]:
+                 dict(overlap=3, fuse=6, tail_split=0), dict(overlap=1, fuse=5, rows_per_chunk=50),
+                 dict(overlap=3, fuse=6, direct_faces=0)]:
         st = csim.Stepper(d, 1.0, 1.0, csim.bc_codes("dddd"))
         st.comm_init(csim.comm_unique_id())
         for k, v in opts.items():
@@ -184,7 +217,7 @@ def test_fuzz_random_torus_cases_vs_oracle(csim):
         dt = 0.1 if (D or vx or vy) else 0.1
         steps = int(rng.integers(2, 26))
         opts = dict(overlap=int(rng.choice([0, 1, 3, 4, 5])), fuse=int(rng.choice([-1, -1, 0, 2, 3, 4, 5, 6, 7])),
-                    rows_per_chunk=int(rng.choice([0, 0, 3, 20])))
+                    rows_per_chunk=int(rng.choice([0, 0, 3, 20])), direct_faces=case % 2)
         u0 = np.zeros((ny + 2, nx + 2))
         u0[1:-1, 1:-1] = rng.standard_normal((ny, nx))
         u0[0, :], u0[-1, :], u0[:, 0], u0[:, -1] = rng.standard_normal(4)
