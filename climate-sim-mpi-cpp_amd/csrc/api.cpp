@@ -1424,6 +1424,9 @@ int csim_stepper_set_option(csim_stepper* s, const char* key, long value) {
     } else if (k == "frame_fence") {
         CSIM_REQUIRE(value >= 0 && value <= 2, "frame_fence must be 0..2");
         s->frame_fence = static_cast<int>(value);
+    } else if (k == "frame_rows") {
+        CSIM_REQUIRE(value >= 0 && value <= 4096, "frame_rows must be 0..4096");
+        s->cfg.frame_rows = static_cast<int>(value);
     } else if (k == "frame_prio") {
         s->frame_prio = value != 0;
     } else if (k == "direct_faces") {
@@ -1472,6 +1475,7 @@ int csim_stepper_get_option(const csim_stepper* s, const char* key, long* value)
     else if (k == "tail_split") *value = s->cfg.tail_split;
     else if (k == "overlap") *value = s->overlap;
     else if (k == "direct_faces") *value = s->direct_faces;
+    else if (k == "frame_rows") *value = s->cfg.frame_rows;
     else if (k == "external_halo") *value = s->external;
     else if (k == "fuse") *value = s->fuse;
     else if (k == "contract") *value = s->contract;

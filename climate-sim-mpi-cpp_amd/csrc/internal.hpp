@@ -69,6 +69,7 @@ struct SweepCfg {
     int xcd_swizzle = 1;
     int tail_split = 1;        // fused launches of two or more rounds of wavefronts end with a region of half-height
                                // chunks (see Tiling); 0 off, 2 experiment (half + quarter height)
+    int frame_rows = 0;        // multi-rank pass: chunk height of the frame's side strips (0 = as thin as the bands)
     int* rows_used = nullptr;  // out: chunk height of the last whole-field / bulk launch (option "last_rows")
 };
 

@@ -681,8 +681,10 @@ hipError_t sweepO_div(const double* in, double* out, int nx, int ny, int pitch, 
     } else if (part == 1 || part == 3) {
         add(0, nstrips, 1, hf, hf);
         add(0, nstrips, ny - hf + 1, ny, hf);
-        add(0, 1, hf + 1, ny - hf, hf);
-        add(nstrips - nright, nright, hf + 1, ny - hf, hf);
+        int hs = hf;  // side strips: taller chunks waste fewer warm-up rows (2 (T - 1) per chunk) but finish later
+        if (cfg.frame_rows >= MAX_FUSE) hs = cfg.frame_rows + (6 - (cfg.frame_rows + 2 * (T - 1)) % 6) % 6;
+        add(0, 1, hf + 1, ny - hf, hs);
+        add(nstrips - nright, nright, hf + 1, ny - hf, hs);
     }
     int nblocks;
     if (part == 3 && split) {  // merged launch: the frame tiles above, then the bulk in the same grid

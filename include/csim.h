@@ -201,6 +201,8 @@ int csim_stepper_sum(csim_stepper* s, double* out);
  *   "direct_faces"   0/1 (default 1), schedule 3: the frame wavefronts copy the cells that form the NEXT pass's faces
  *                    straight into the RCCL send buffers before they publish the flag (0: a pack kernel on the
  *                    comm stream does it after the flag)
+ *   "frame_rows"     experiment: chunk height of the frame's side strips in a multi-rank pass (0 = default, the 12-14
+ *                    rows of the bottom/top bands; measured best)
  *   "external_halo"  0/1 the caller carries the faces (csim_stepper_halo_* / _faces_*)
  *   "profile"        0 off, k >= 1: HIP events around the sweep launch(es) of every k-th pass
  *                    (csim_stepper_kernel_time)
