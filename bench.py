@@ -233,6 +233,7 @@ def main():
     ap.add_argument("--overlap-mode", type=int, default=-1,
                     help="N > 1: -1 pick the fastest exchange schedule on this node; 0, 1, 3, 4, 5 force one")
     ap.add_argument("--lds-bytes", type=int, default=0, help="occupancy limiter experiment (see csim.h)")
+    ap.add_argument("--fused-2c", type=int, default=-1, help="0/1: E - 2c as one fma under the overflow guard (bit-identical either way; default: on)")
     ap.add_argument("--tail-split", type=int, default=-1, help="0/1: half-height chunks at the end of a whole-field launch (default: on)")
     ap.add_argument("--fuse", type=int, default=-1,
                     help="time steps per HBM pass: -1 auto (cheapest split of the run into passes of 2..7 steps), 0 off, 2..7")
@@ -311,6 +312,8 @@ def main():
         st.set_option("lds_bytes", args.lds_bytes)
     if args.tail_split >= 0:
         st.set_option("tail_split", args.tail_split)
+    if args.fused_2c >= 0:
+        st.set_option("fused_2c", args.fused_2c)
     st.init_gaussian(1.0, 0.05, 0.5, 0.5)
     dt = min(PHYS["dt"], csim.safe_dt(1.0, 1.0, PHYS["vx"], PHYS["vy"], PHYS["D"]))
 
@@ -536,7 +539,8 @@ def main():
                 valu_busy_frac_under_counters=(valu["SQ_ACTIVE_INST_VALU"] / (valu["GRBM_GUI_ACTIVE"] / 8.0 / 4.0 * 1024.0))
                 if valu.get("SQ_ACTIVE_INST_VALU") and valu.get("GRBM_GUI_ACTIVE") else None,
                 source=f"profiles/sq_valu.json ({valu.get('kernel')}, {valu.get('nx')}x{valu.get('ny')}): SQ_INSTS_VALU "
-                       f"per launch, {fp64_share:.3f} of them fp64 add/mul (rest: DPP lane shifts), clock = "
+                       f"per launch, {fp64_share:.3f} of them fp64 add/mul/fma (14 per cell: E - 2c, N - 2c are one exact fma "
+                       f"each; rest: DPP lane shifts, 2 screening compares per row), clock = "
                        f"GRBM_GUI_ACTIVE / 8 / kernel time in that PMC run")
         n_launch_total = args.steps / T
         line = {

@@ -71,6 +71,16 @@ Phys make_phys(double dx, double dy, double D, double dt, double vx, double vy, 
         p.aS = static_cast<double>(ky + (vy >= 0.0 ? acy : 0.0L));
         p.aN = static_cast<double>(ky + (vy >= 0.0 ? 0.0L : acy));
     }
+    // fused E - 2c (diffuse_term<., true>): max|u| grows by at most g per step — the sum of the magnitudes of
+    // what multiplies the five points, with room for the 15 roundings — so a tile whose inputs stay below
+    // 2^1022 / g^MAX_FUSE cannot reach 2^1023 at any level of a pass.  Parameters so far from stable that
+    // this bound drops below 2^900 switch the fused form off.
+    {
+        const double g = (1.0 + 4.0 * std::fabs(p.kdiff) * (1.0 / p.dx2 + 1.0 / p.dy2) +
+                          2.0 * std::fabs(p.mdt) * (std::fabs(vx) / std::fabs(dx) + std::fabs(vy) / std::fabs(dy))) * (1.0 + 1e-9);
+        const double thr = std::ldexp(1.0, 1022) / std::pow(g, MAX_FUSE);
+        p.fast_thr = (std::isfinite(g) && thr >= std::ldexp(1.0, 900)) ? thr : 0.0;
+    }
     if (contract) p.div_mode = 3;
     return p;
 }
@@ -154,6 +164,8 @@ struct csim_stepper {
     unsigned long long* frame_flag = nullptr;
     unsigned long long pass_no = 0;
     int frame_fence = 0, frame_prio = 1;  // experiment switches of mode 3, see FrameSync
+    int fused_2c = 1;         // k_sweepO_dpp's interior body fuses E - 2c into one fma under the overflow guard (Phys::fast_thr)
+    int fused_2c_active = 0;  // read-only: whether the last run's parameters allowed it
     int direct_faces = 1;                 // merged launch: the frame wavefronts fill send2[] themselves (no pack kernel)
     bool bulk_first_run = false;          // the current csim_stepper_run uses pass_fused_bulk_first
     // asynchronous snapshot of the interior (device staging copy + pinned host buffer + I/O stream)
@@ -1322,7 +1334,9 @@ int csim_stepper_tune(csim_stepper* s, double D, double dt, double vx, double vy
     CSIM_REQUIRE(s, "null stepper");
     const int depth = fused_depth(s);
     if (depth < 2 || s->tuned || s->cfg.rows_per_chunk != 0) return CSIM_OK;
-    return tune_rows(s, make_phys(s->dx, s->dy, D, dt, vx, vy, s->contract != 0), depth);
+    Phys p = make_phys(s->dx, s->dy, D, dt, vx, vy, s->contract != 0);
+    if (!s->fused_2c) p.fast_thr = 0.0;
+    return tune_rows(s, p, depth);
 }
 
 int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy, int nsteps) {
@@ -1343,7 +1357,9 @@ int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy,
     } else if (s->multi && !s->comm) {
         return fail(CSIM_ERR_STATE, "multi-rank stepper needs csim_stepper_comm_init before run");
     }
-    const Phys p = make_phys(s->dx, s->dy, D, dt, vx, vy, s->contract != 0);
+    Phys p = make_phys(s->dx, s->dy, D, dt, vx, vy, s->contract != 0);
+    if (!s->fused_2c) p.fast_thr = 0.0;
+    s->fused_2c_active = p.fast_thr > 0.0 && p.div_mode != 3;
     const GhostArgs g = ghost_args(s);
     if (s->multi && s->external && nsteps >= 2) return pass_fused(s, p, nsteps, 0);
     // The ghost ring left in the field must be exactly the reference's: the halos / boundary values
@@ -1431,6 +1447,8 @@ int csim_stepper_set_option(csim_stepper* s, const char* key, long value) {
         s->frame_prio = value != 0;
     } else if (k == "direct_faces") {
         s->direct_faces = value != 0;
+    } else if (k == "fused_2c") {
+        s->fused_2c = value != 0;
     } else if (k == "external_halo") {
         s->external = value != 0;
         s->halo_fresh = false;
@@ -1475,6 +1493,8 @@ int csim_stepper_get_option(const csim_stepper* s, const char* key, long* value)
     else if (k == "tail_split") *value = s->cfg.tail_split;
     else if (k == "overlap") *value = s->overlap;
     else if (k == "direct_faces") *value = s->direct_faces;
+    else if (k == "fused_2c") *value = s->fused_2c;
+    else if (k == "fused_2c_active") *value = s->fused_2c_active;
     else if (k == "frame_rows") *value = s->cfg.frame_rows;
     else if (k == "external_halo") *value = s->external;
     else if (k == "fuse") *value = s->fuse;

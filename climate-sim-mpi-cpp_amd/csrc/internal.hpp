@@ -53,6 +53,8 @@ struct Phys {
     int div_mode;       // 0: dx == dy == 1 (x/1 is x)   1: exact reciprocal multiply   2: IEEE divide
                         // 3: option "contract" — the coefficient form below (not bit-identical)
     double a0, aW, aE, aS, aN;  // u' = a0 c + aW W + aE E + aS S + aN N, the same update as one 5-point stencil
+    double fast_thr;    // > 0: k_sweepO_dpp may fuse E - 2c into one fma on tiles whose loaded values are all below
+                        // this magnitude (no 2c of any level can overflow then); 0: always the plain form
 };
 Phys make_phys(double dx, double dy, double D, double dt, double vx, double vy, bool contract = false);
 

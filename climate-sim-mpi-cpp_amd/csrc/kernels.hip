@@ -33,12 +33,23 @@ namespace csim {
 // DIV 0: dx == dy == 1, x/1 == x.  DIV 1: all divisors are powers of two, so x * (1/d) is the
 // correctly rounded quotient too (bit-identical to x/d).  DIV 2: true IEEE fp64 division.
 // -------------------------------------------------------------------------------------------
-template <int DIV>
+// FAST: E - 2c as ONE operation, fma(-2, c, E).  2c is exact in binary floating point (subnormals included), so
+// the fused form rounds the same real number E - 2c once, exactly like the subtraction does — unless 2c
+// overflows (|c| >= 2^1023), where the reference gets +-inf and the fma a finite number.  Only k_sweepO_dpp's
+// interior body uses it, under a guard that re-runs the tile with the plain form if that could happen (see
+// sweepO_march); it removes one of the 15 fp64 operations per cell.
+template <int DIV, bool FAST = false>
 __device__ __forceinline__ double diffuse_term(double c, double W, double E, double S, double N,
                                                const Phys& p) {
-    const double tc = 2.0 * c;
-    double lx = (E - tc) + W;
-    double ly = (N - tc) + S;
+    double lx, ly;
+    if (FAST) {
+        lx = __builtin_fma(-2.0, c, E) + W;
+        ly = __builtin_fma(-2.0, c, N) + S;
+    } else {
+        const double tc = 2.0 * c;
+        lx = (E - tc) + W;
+        ly = (N - tc) + S;
+    }
     if (DIV == 1) {
         lx = lx * p.rdx2;
         ly = ly * p.rdy2;
@@ -84,7 +95,7 @@ __device__ __forceinline__ double advect_term(double c, double W, double E, doub
 // it is, a0 c + aW W + aE E + aS S + aN N with host-made coefficients (make_phys), evaluated as one
 // multiply and four FMAs instead of 15 non-FMA operations.  Differs from the reference's rounding by a
 // few ulp per step (tests: L_inf < 1e-10 after 1000 steps, the north-star tolerance).
-template <int DIV, int SX = -1, int SY = -1>
+template <int DIV, int SX = -1, int SY = -1, bool FAST = false>
 __device__ __forceinline__ double cell(double c, double W, double E, double S, double N,
                                        const Phys& p) {
     if (DIV == 3) {
@@ -94,7 +105,7 @@ __device__ __forceinline__ double cell(double c, double W, double E, double S, d
         o = __builtin_fma(p.aS, S, o);
         return __builtin_fma(p.aN, N, o);
     }
-    const double o = diffuse_term<DIV>(c, W, E, S, N, p);
+    const double o = diffuse_term<DIV, FAST>(c, W, E, S, N, p);
     return o + advect_term<DIV, SX, SY>(c, W, E, S, N, p);
 }
 
@@ -318,8 +329,14 @@ struct OverlapGeom {
     static constexpr int STRIDE = WAVE_COLS - 2 * TP;  // output columns per wavefront
 };
 
-template <int DIV, int T, bool EDGE, int SX, int SY>
-__device__ __forceinline__ void sweepO_march(const double* __restrict__ in, double* __restrict__ out,
+// FAST (interior body only): the cell update with E - 2c, N - 2c fused (diffuse_term<., true>), bit-identical to
+// the plain form as long as no 2c overflows.  Guard: every value the tile loads is compared with p.fast_thr =
+// 2^1022 / g^MAX_FUSE, g = the host's bound on the growth of max|u| per step; below it no level of the pass can
+// reach 2^1023.  The march returns true if any lane saw a value that is not below the threshold (NaN and Inf
+// included) and the caller then repeats the tile with the plain form — same loads, same stores, the reference's
+// own operations.  Cost: two compares per lane and loaded row against 2 T multiplies saved.
+template <int DIV, int T, bool EDGE, int SX, int SY, bool FAST = false>
+__device__ __forceinline__ bool sweepO_march(const double* __restrict__ in, double* __restrict__ out,
                                              int nx, int ny, int pitch, int jb, int je, int g0, int lane,
                                              int kl, int kr, const Phys& p, const Bc2& bc,
                                              const FinLines& fin, bool fin_l, bool fin_r, bool wt) {
@@ -355,6 +372,15 @@ __device__ __forceinline__ void sweepO_march(const double* __restrict__ in, doub
     double2 L[T][3];
 #pragma unroll
     for (int q = 0; q < 6; ++q) L0[q] = load(min(r_first - 1 + q, last_row));
+    bool big = false;  // FAST: some loaded value is not below the threshold
+    auto screen = [&](const double2& v) {
+        big |= !(__builtin_fabs(v.x) < p.fast_thr);
+        big |= !(__builtin_fabs(v.y) < p.fast_thr);
+    };
+    if (FAST) {  // every later row is screened when it is the `n` of level 1
+        screen(L0[0]);
+        screen(L0[1]);
+    }
 #pragma unroll
     for (int l = 0; l < T; ++l)
 #pragma unroll
@@ -385,8 +411,9 @@ __device__ __forceinline__ void sweepO_march(const double* __restrict__ in, doub
                     {
                         const double Wx = shift_from_prev(c.y);
                         const double Ey = shift_from_next(c.x);
-                        o.x = cell<DIV, SX, SY>(c.x, Wx, c.y, s.x, n.x, p);
-                        o.y = cell<DIV, SX, SY>(c.y, c.x, Ey, s.y, n.y, p);
+                        o.x = cell<DIV, SX, SY, FAST>(c.x, Wx, c.y, s.x, n.x, p);
+                        o.y = cell<DIV, SX, SY, FAST>(c.y, c.x, Ey, s.y, n.y, p);
+                        if (FAST && l == 1) screen(n);
                     }
                     if (EDGE && l < T) {
                         const bool gb = rho == 0 && kb != 3, gt = rho == ny + 1 && kt != 3;
@@ -459,6 +486,7 @@ __device__ __forceinline__ void sweepO_march(const double* __restrict__ in, doub
         if (niter > 6) group(std::integral_constant<int, 1>{}, 6);
         for (int k0 = 12; k0 < niter; k0 += 6) group(std::integral_constant<int, 2>{}, k0);
     }
+    return FAST && __builtin_amdgcn_ballot_w64(big) != 0;
 }
 
 // Tiles of one launch: up to four rectangular regions of (strip, chunk) tiles, numbered
@@ -546,8 +574,15 @@ __global__ __launch_bounds__(256) void k_sweepO_dpp(const double* __restrict__ i
         // (29 % of a 4096 x 8192 launch, tools/wavetrace.hip): give them issue priority.
         __builtin_amdgcn_s_setprio(3);
         sweepO_march<DIV, T, true, SX, SY>(in, out, nx, ny, pitch, jb, je, g0, lane, kl, kr, p, bc, fin, first, last, wt);
-    } else
-        sweepO_march<DIV, T, false, SX, SY>(in, out, nx, ny, pitch, jb, je, g0, lane, kl, kr, p, bc, fin, false, false, wt);
+    } else {
+        bool redo = true;
+        if (DIV != 3 && p.fast_thr > 0.0)
+            redo = sweepO_march<DIV, T, false, SX, SY, true>(in, out, nx, ny, pitch, jb, je, g0, lane, kl, kr, p, bc, fin, false, false, wt);
+        if (redo) {
+            keep_branch();
+            sweepO_march<DIV, T, false, SX, SY>(in, out, nx, ny, pitch, jb, je, g0, lane, kl, kr, p, bc, fin, false, false, wt);
+        }
+    }
     if (frame_tile && fs.flag) {
         // Merged launch: the comm stream is parked on `flag` (hipStreamWaitValue64) and goes on to pack and
         // send the next pass's faces as soon as EVERY frame tile is in memory — while this very kernel is

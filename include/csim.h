@@ -186,6 +186,12 @@ int csim_stepper_sum(csim_stepper* s, double* out);
  *                    stencil a0 c + aW W + aE E + aS S + aN N in FMA form (5 instead of 15 fp64
  *                    operations per cell); rounding differs by a few ulp per step, L_inf vs the reference
  *                    stays far below the 1e-10 tolerance (tests/test_gpu_contract.py).
+ *   "fused_2c"       0/1 (default 1), bit-identical either way: the interior body of the multi-step sweep evaluates
+ *                    E - 2c and N - 2c as one fma(-2, c, .) each — 2c is exact, so the result is the reference's —
+ *                    and every tile screens the values it loads: if one is so large that some 2c of the pass
+ *                    could overflow (or is NaN / Inf), the tile is recomputed with the reference's own operation
+ *                    sequence.  14 instead of 15 fp64 operations per cell.  "fused_2c_active" (read-only): whether
+ *                    the last run's parameters allowed it (growth bound per step, see make_phys)
  *   "fuse"           time steps per HBM pass: -1 auto (the cheapest split of a run into passes of 2..7 steps, e.g.
  *                    1000 = 166 x 6 + 4, 20 = 7 + 7 + 6), 0/1 off, 2..7 balanced passes of at most that depth
  *   "variant"        single-step kernel family: 0 auto, 1 dpp, 2 lds, 3 naive

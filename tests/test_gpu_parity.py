@@ -291,6 +291,73 @@ def test_subnormal_huge_and_nonfinite_values(csim):
         assert np.array_equal(got[ok], want[ok])
 
 
+@pytest.mark.parametrize("dx,dy", [(1.0, 1.0), (0.5, 2.0), (0.7, 1.3)])
+@pytest.mark.parametrize("fuse", [2, 4, 6, 7])
+def test_fused_2c_guard_values_near_overflow(csim, dx, dy, fuse):
+    """The interior body of the multi-step sweep fuses E - 2c into fma(-2, c, E), which equals the reference's
+    two operations unless 2c overflows; tiles screen their inputs and fall back to the reference's own sequence.
+    A field with many interior-body tiles (3+ strips, short chunks) carries patches around the critical
+    magnitudes: 1e300 (below the screen: fused form, finite), 4e307 (above the screen, 2c still finite),
+    1.2e308 >= 2^1023 (2c overflows in the reference: +-inf, then NaN), plus Inf and NaN cells.  The result must
+    equal the oracle's: same NaN cells, every other cell bit for bit (Inf signs included) — with the fused form
+    on (default) and off."""
+    nx, ny = 700, 160
+    steps = fuse + 3
+    D, vx, vy, dt = 0.05, 0.5, -0.25, 0.1
+    dt = min(dt, csim.safe_dt(dx, dy, vx, vy, D))
+    rng = np.random.default_rng(31)
+    u0 = np.zeros((ny + 2, nx + 2))
+    u0[1:-1, 1:-1] = rng.standard_normal((ny, nx))
+    u0[30:38, 150:170] *= 1e300
+    u0[60:66, 300:330] *= 4e307 / 3
+    u0[90:97, 420:450] = 1.2e308 * np.sign(u0[90:97, 420:450])
+    u0[120, 260] = np.inf
+    u0[125, 520] = -np.inf
+    u0[45, 380] = np.nan
+    u0[130:134, 200:230] *= 1e-310
+    want = u0.copy()
+    with np.errstate(all="ignore"):
+        ora.run_single(want, dx, dy, D, vx, vy, dt, ora.bc_codes("dddd"), steps)
+    assert np.isinf(want).any() and np.isnan(want).any() and np.isfinite(want).sum() > 0.5 * want.size
+    for fused in (1, 0):
+        st = csim.Stepper.single(nx, ny, dx, dy, csim.bc_codes("dddd"))
+        for k, v in dict(fuse=fuse, rows_per_chunk=18, fused_2c=fused).items():
+            st.set_option(k, v)
+        st.upload(u0)
+        st.run(D, dt, vx, vy, steps)
+        assert st.get_option("fused_2c_active") == fused
+        got = st.download()
+        st.close()
+        assert np.array_equal(np.isnan(got), np.isnan(want)), (fused, int((np.isnan(got) != np.isnan(want)).sum()))
+        ok = ~np.isnan(want)
+        assert np.array_equal(got[ok].view(np.int64), want[ok].view(np.int64)), fused
+
+
+def test_fused_2c_is_switched_off_for_wildly_unstable_parameters(csim):
+    """the screen's threshold divides 2^1022 by the seventh power of the per-step growth bound; parameters whose
+    bound leaves no room (dt far beyond any stability limit through the C ABI, which does not clamp) must run the
+    plain form, and the result must still be the oracle's"""
+    nx, ny, steps = 500, 90, 8
+    rng = np.random.default_rng(5)
+    u0 = np.zeros((ny + 2, nx + 2))
+    u0[1:-1, 1:-1] = rng.standard_normal((ny, nx))
+    D, vx, vy, dt = 3.0e18, 0.5, 0.25, 1.0
+    want = u0.copy()
+    with np.errstate(all="ignore"):
+        ora.run_single(want, 1.0, 1.0, D, vx, vy, dt, ora.bc_codes("dddd"), steps)
+    st = csim.Stepper.single(nx, ny, 1.0, 1.0, csim.bc_codes("dddd"))
+    st.set_option("fuse", 6)
+    st.set_option("rows_per_chunk", 18)
+    st.upload(u0)
+    st.run(D, dt, vx, vy, steps)
+    assert st.get_option("fused_2c_active") == 0
+    got = st.download()
+    st.close()
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    ok = ~np.isnan(want)
+    assert np.array_equal(got[ok].view(np.int64), want[ok].view(np.int64))
+
+
 def test_fused_step_equals_copy_diffusion_advection(csim):
     """csim_fused_step == std::copy + diffusion_step + advection_step (main.cpp:104-107)."""
     rng = np.random.default_rng(3)

@@ -103,7 +103,7 @@ def main():
             e = dict(kernel=chunk[0][1], nx=seq["nx"], ny=seq["ny"], bc=s["bc"], steps_per_launch=T,
                      rows_per_chunk=s["rows_per_chunk"], kernel_us_under_counters=m["ns"] / 1e3,
                      clock_ghz=(m["GRBM_GUI_ACTIVE"] / 8 / m["ns"]) if m["ns"] else None,
-                     fp64_share=(15.0 * 2 * T) / (15.0 * 2 * T + 4 * T) if T > 1 else 30.0 / 36.0)
+                     fp64_share=(14.0 * 2 * T) / (14.0 * 2 * T + 4 * T + 2) if T > 1 else 30.0 / 36.0)
             for n in ("SQ_INSTS_VALU", "SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU",
                       "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE"):
                 if n in m:
@@ -118,8 +118,9 @@ def main():
         json.dump(dict(tag=tag, collected_by="tools/gpu_pmc.sh: rocprofv3 --pmc SQ_* GRBM_GUI_ACTIVE --kernel-trace on "
                        "tools/pmc_workload.py", note="SQ_INSTS_VALU = wave-level VALU instructions per launch; "
                        "clock_ghz = GRBM_GUI_ACTIVE / 8 XCDs / kernel time of the same (counter-slowed) run; "
-                       "fp64_share = fp64 add/mul among the VALU instructions of the steady-state body "
-                       "(30 T fp64 + 4 T DPP moves per lane-row at depth T)",
+                       "fp64_share = fp64 add/mul/fma among the VALU instructions of the steady-state body "
+                       "(28 T fp64 — E - 2c and N - 2c are one fma each — + 4 T DPP moves + 2 screening compares "
+                       "per lane-row at depth T)",
                        entries=entries, all=out), open(os.path.join(dst, "sq_valu.json"), "w"), indent=1)
         for e in entries:
             print(f"  SQ T={e['steps_per_launch']} ry={e['rows_per_chunk']} VALU insts {e.get('SQ_INSTS_VALU', 0) / 1e6:.1f} M "
