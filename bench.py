@@ -30,7 +30,8 @@ Rank 0 prints ONE JSON line.  Extra objects:
   rate, which exceeds the HBM peak by construction, is reported beside them as
   `step_equivalent_gbs` / `step_equivalent_x_peak` and never as `frac`.
 `roofline_valu`: the resource that actually binds the T >= 4 kernels — fp64 VALU issue (the
-  reference's own 15 non-FMA fp64 operations per cell update; FMA contraction would change bits).
+  reference's own 15 fp64 operations per cell update; contraction would change bits, except for the one
+  fusion that is exact, E - 2c as fma(-2, c, E), which the kernel uses under an overflow screen: 14 issued).
 `cpu_baseline` (N = 1): the compiled reference objects (oracle/_ref/ref_run under mpirun) and the
   oracle port (checked / unchecked accessor flavours) on bounded samples, host core counts stated.
 """
@@ -504,8 +505,8 @@ def main():
             "note": "frac = PMC traffic / live kernel time / 8 TB/s.  step_equivalent_* counts 16 B per cell-UPDATE "
                     "(SURVEY §8d) and exceeds the peak because T time levels stay in registers per pass; it is "
                     "the figure to compare with a one-step-per-pass sweep, not a bandwidth.  A deeper pass LOWERS frac while "
-                    "raising the throughput (16384^2: T = 6 0.54, T = 7 0.46 at +0.9 % Mcell-updates/s): the kernel is bound "
-                    "by fp64 VALU issue (roofline_valu: VALUs ~96 % busy at the clock the chip holds), not by HBM",
+                    "raising the throughput (16384^2: T = 6 ~0.55, T = 7 ~0.48 at +0.9 % Mcell-updates/s): the kernel is bound "
+                    "by fp64 VALU issue (roofline_valu: VALUs ~95 % busy at the clock the chip holds), not by HBM",
         }
         ops_per_update = FP64_OPS_PER_UPDATE if not args.contract else 5
         useful_tops = local_cells * T * ops_per_update / secs / 1e12
