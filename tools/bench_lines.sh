@@ -1,0 +1,13 @@
+#!/bin/bash
+# tools/bench_lines.sh — the bench lines kept under profiles/ (run on the GPU box through gpurun; copy gpurun_out/lines/*.json to profiles/)
+set -e
+mkdir -p gpurun_out/lines
+python bench.py > gpurun_out/lines/r02_bench_line.json 2>/dev/null
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/lines/r02_bench_line_steps20.json 2>/dev/null
+python bench.py --bc nnnn --no-cpu-baseline > gpurun_out/lines/r02_bench_line_nnnn.json 2>/dev/null
+python bench.py --bc dnpd --no-cpu-baseline > gpurun_out/lines/r02_bench_line_dnpd.json 2>/dev/null
+python bench.py --contract 1 --no-cpu-baseline > gpurun_out/lines/r02_bench_line_contract.json 2>/dev/null
+CSIM_BENCH_SELF_TORUS=1 python bench.py --nx 4096 --ny 8192 --no-cpu-baseline > gpurun_out/lines/r02_bench_selftorus_4096x8192.json 2>/dev/null
+CSIM_BENCH_SELF_TORUS=1 python bench.py --nx 4096 --ny 8192 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/lines/r02_bench_selftorus_4096x8192_steps20.json 2>/dev/null
+for f in gpurun_out/lines/*.json; do python3 -c "
+import sys,json; d=json.loads(open('$f').read().strip().splitlines()[-1]); print('$f', round(d['value']), d['roofline']['frac'] if d.get('roofline') else None, d['roofline'].get('kernel_avg_ms') if d.get('roofline') else None)"; done
