@@ -17,7 +17,8 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "liboracle_cpu.so")
+# CSIM_ORACLE_SO: another build of cpu_stepper.c (tools/cpu_sanitize.sh points it at an ASan/UBSan one)
+LIB_PATH = os.environ.get("CSIM_ORACLE_SO") or os.path.join(HERE, "liboracle_cpu.so")
 REF_RUN = os.path.join(HERE, "_ref", "ref_run")
 MPIRUN = "/opt/conda/bin/mpirun"
 

@@ -12,7 +12,8 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DRV = os.path.join(ROOT, "climate-sim-mpi-cpp_amd", "driver")
-TOOL = os.path.join(DRV, "csim_hosttool")
+# CSIM_HOSTTOOL: another build of the host tool (tools/cpu_sanitize.sh points it at an ASan/UBSan one)
+TOOL = os.environ.get("CSIM_HOSTTOOL") or os.path.join(DRV, "csim_hosttool")
 
 
 @pytest.fixture(scope="module", autouse=True)
