@@ -353,13 +353,21 @@ def main():
             while time.perf_counter() < box[0]:
                 pass
 
-    # untimed: clock ramp (also triggers the stepper's one-off rows-per-chunk trial), then W warm-up steps
+    # untimed: the W warm-up steps first (cold: first launches of the kernels, code loading), then the clock ramp
+    # in bursts shaped like the timed run (also triggers the stepper's one-off rows-per-chunk trial).  The ramp comes
+    # LAST so that nothing but the synchronisation stands between steady-state load and the timed region: a first
+    # launch of a new kernel kind stalls the host for ~2 ms (code loading), the idle GPU drops out of its sustained
+    # power state, and the next few launches then run 5-15 % slower than in steady state — on a 20-step timed
+    # region (three launches) that was the difference between 1.45 and 1.52 M (kernel timelines: tools/gpu_trace_steps20.sh)
+    st.tune(PHYS["D"], dt, PHYS["vx"], PHYS["vy"])  # the one-off chunk-height trial a first long run() would do (local, no exchange)
+    advance(args.warmup)
+    burst = max(1, min(args.steps, 60))
     ramp_steps = 0
     t_ramp = time.perf_counter()
     while args.ramp_seconds > 0:
-        advance(60)
+        advance(burst)
         st.sync()
-        ramp_steps += 60
+        ramp_steps += burst
         done = time.perf_counter() - t_ramp >= args.ramp_seconds
         if multi:  # every rank must take the same number of steps: decide together
             t = torch.tensor([1 if done else 0], dtype=torch.int64)
@@ -412,11 +420,14 @@ def main():
         exchange_modes["chosen"] = best
     elif multi and args.overlap_mode >= 0:
         st.set_option("overlap", args.overlap_mode)
-    advance(args.warmup)
-    barrier()
+    if multi and args.ramp_seconds > 0:  # one more burst with the schedule just chosen
+        advance(burst)
+        ramp_steps += burst
     # HIP events around every sweep launch at N = 1; around every 8th pass at N > 1, where the two
-    # event records per pass would cost ~10 % of a 170 us pass
+    # event records per pass would cost ~10 % of a 170 us pass.  (Set before the barrier: nothing but the clock
+    # read stands between the synchronisation and the first timed launch, so the GPU idles as briefly as it can.)
     st.set_option("profile", 8 if multi else 1)
+    barrier()
     st.reset_timers()
     t0 = time.perf_counter()
     advance(args.steps)

@@ -198,7 +198,10 @@ struct csim_stepper {
     bool tuned = false;
     std::vector<hipEvent_t> ev_pool;  // start/stop pairs around sweep launches
     std::vector<int> ev_steps;        // time steps covered by each timed launch
+    std::vector<long> ev_count;       // launches bracketed by each pair (see prof_begin: runs of equal launches)
     size_t ev_used = 0;
+    int prof_open_kind = 0;           // > 0: a bracket of launches of that kind is open on the compute stream
+    long prof_open_slot = -1;
     static constexpr int PROF_COMM = MAX_FUSE + 1;  // comm-stream chain of a pass: pack, RCCL group, unpack, ghost fill
     double prof_ms[MAX_FUSE + 2]{};     // indexed by time steps per launch (1..MAX_FUSE), [PROF_COMM]
     long prof_launches[MAX_FUSE + 2]{};
@@ -884,8 +887,12 @@ int csim_stepper_exchange_halos(csim_stepper* s) {
     return CSIM_OK;
 }
 
+static int prof_close(csim_stepper* s);
+
 static int prof_fold(csim_stepper* s) {
     if (s->ev_used == 0) return CSIM_OK;
+    int rc0 = prof_close(s);
+    if (rc0) return rc0;
     CSIM_HIP(hipStreamSynchronize(s->s_comp));
     CSIM_HIP(hipStreamSynchronize(s->s_comm));
     for (size_t k = 0; k + 1 < s->ev_used; k += 2) {
@@ -893,7 +900,7 @@ static int prof_fold(csim_stepper* s) {
         CSIM_HIP(hipEventElapsedTime(&ms, s->ev_pool[k], s->ev_pool[k + 1]));
         const int t = s->ev_steps[k / 2];
         s->prof_ms[t] += ms;
-        s->prof_launches[t] += 1;
+        s->prof_launches[t] += s->ev_count[k / 2];
     }
     s->ev_used = 0;
     return CSIM_OK;
@@ -906,11 +913,15 @@ static int prof_start(csim_stepper* s, int kind, hipStream_t st, long* slot) {
     if (!s->prof_active) return CSIM_OK;
     while (s->ev_pool.size() < s->ev_used + 2) {
         hipEvent_t ev;
-        CSIM_HIP(hipEventCreate(&ev));
+        // timing only: without the system-scope fence a default event performs when it is recorded (cache
+        // write-back and invalidation between the kernels it brackets — the very thing being timed)
+        CSIM_HIP(hipEventCreateWithFlags(&ev, hipEventDisableSystemFence));
         s->ev_pool.push_back(ev);
     }
     if (s->ev_steps.size() < s->ev_pool.size() / 2) s->ev_steps.resize(s->ev_pool.size() / 2);
+    if (s->ev_count.size() < s->ev_pool.size() / 2) s->ev_count.resize(s->ev_pool.size() / 2);
     s->ev_steps[s->ev_used / 2] = kind;
+    s->ev_count[s->ev_used / 2] = 1;
     CSIM_HIP(hipEventRecord(s->ev_pool[s->ev_used], st));
     *slot = static_cast<long>(s->ev_used);
     s->ev_used += 2;
@@ -923,8 +934,38 @@ static int prof_stop(csim_stepper* s, long slot, hipStream_t st) {
     return CSIM_OK;
 }
 
+// the stop event of an open bracket (see prof_begin)
+static int prof_close(csim_stepper* s) {
+    if (s->prof_open_kind == 0) return CSIM_OK;
+    s->prof_open_kind = 0;
+    return prof_stop(s, s->prof_open_slot, s->s_comp);
+}
+
 static int prof_begin(csim_stepper* s, int steps) {
     constexpr size_t POOL = 2048;
+    if (s->profile == 1 && !s->multi) {
+        // Single rank, every pass timed: ONE bracket per run of equal launches instead of one per launch.  An
+        // event between two launches is a barrier: the next launch cannot start its first wavefronts while the
+        // previous one drains, which costs ~5 % of a 1.2 ms launch (kernel timelines of bench.py --steps 20) —
+        // the measurement would slow down what it measures.  The figure reported per kind is then the
+        // start-to-end time of the run divided by its launches (ghost fills between them included: ~5 us).
+        s->prof_active = false;
+        if (s->prof_open_kind == steps) {
+            s->ev_count[static_cast<size_t>(s->prof_open_slot) / 2] += 1;
+            return CSIM_OK;
+        }
+        int rc = prof_close(s);
+        if (rc) return rc;
+        if (s->ev_used + 4 > POOL) {
+            rc = prof_fold(s);
+            if (rc) return rc;
+        }
+        s->prof_active = true;  // prof_start looks at it
+        rc = prof_start(s, steps, s->s_comp, &s->prof_open_slot);
+        s->prof_active = false;
+        if (rc == CSIM_OK) s->prof_open_kind = steps;
+        return rc;
+    }
     // profile = k > 1: only every k-th pass is bracketed (two event records cost a few microseconds
     // of stream time each, which shows on the ~170 us passes of a small multi-rank tile)
     s->prof_active = s->profile > 0 && (s->prof_counter++ % s->profile) == 0;
@@ -1176,8 +1217,8 @@ static int tune_rows(csim_stepper* s, const Phys& p, int T) {
             if (b) (void)hipEventDestroy(b);
         }
     } ev;
-    CSIM_HIP(hipEventCreate(&ev.a));
-    CSIM_HIP(hipEventCreate(&ev.b));
+    CSIM_HIP(hipEventCreateWithFlags(&ev.a, hipEventDisableSystemFence));  // timing only
+    CSIM_HIP(hipEventCreateWithFlags(&ev.b, hipEventDisableSystemFence));
     const hipEvent_t e0 = ev.a, e1 = ev.b;
     CSIM_HIP(hipStreamSynchronize(s->s_comp));
     SweepCfg cfg = s->cfg;
@@ -1388,7 +1429,7 @@ int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy,
         }
         if (rc) return rc;
     }
-    return CSIM_OK;
+    return prof_close(s);
 }
 
 int csim_stepper_sync(csim_stepper* s) {
