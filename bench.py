@@ -350,6 +350,11 @@ def main():
             # and spin up to it, so that every rank enters the timed region within a microsecond of the others.
             box = [time.perf_counter() + 0.003 if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
+            # ... under load: a GPU that idles through these 3 ms leaves its sustained power state and runs the
+            # first launches afterwards 5-15 % slower (tools/gpu_trace_steps20.sh) — a third of a 20-step region at
+            # 8 GPUs.  Local launches that neither advance the field nor communicate, ending ~0.3 ms before the start.
+            if halo == "rccl":
+                st.keep_warm(PHYS["D"], dt, PHYS["vx"], PHYS["vy"], max(0.0, box[0] - time.perf_counter() - 0.0003))
             while time.perf_counter() < box[0]:
                 pass
 

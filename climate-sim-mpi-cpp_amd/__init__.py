@@ -137,6 +137,7 @@ def lib() -> C.CDLL:
         "csim_stepper_faces_unpack": (i, [vp, i, C.POINTER(dp)]),
         "csim_stepper_run": (i, [vp, d, d, d, d, i]),
         "csim_stepper_tune": (i, [vp, d, d, d, d]),
+        "csim_stepper_keep_warm": (i, [vp, d, d, d, d, d]),
         "csim_pass_schedule": (i, [i, i, C.c_long, i, ip, i, C.POINTER(C.c_long)]),
         "csim_stepper_sync": (i, [vp]),
         "csim_stepper_minmax": (i, [vp, dp]),
@@ -432,6 +433,10 @@ class Stepper:
 
     def tune(self, D, dt, vx, vy):
         _ck(lib().csim_stepper_tune(self._h, D, dt, vx, vy))
+
+    def keep_warm(self, D, dt, vx, vy, seconds):
+        """load without effect on the field for about `seconds` (see csim_stepper_keep_warm)"""
+        _ck(lib().csim_stepper_keep_warm(self._h, D, dt, vx, vy, float(seconds)))
 
     def get_option(self, key: str) -> int:
         v = C.c_long()

@@ -4,6 +4,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -1378,6 +1379,33 @@ int csim_stepper_tune(csim_stepper* s, double D, double dt, double vx, double vy
     Phys p = make_phys(s->dx, s->dy, D, dt, vx, vy, s->contract != 0);
     if (!s->fused_2c) p.fast_thr = 0.0;
     return tune_rows(s, p, depth);
+}
+
+// Load without effect: whole-tile launches cur -> nxt of the multi-step sweep without a swap (what tune_rows
+// does), one at a time, until the next one would end after `seconds`.  No exchange, no ghost fill: the scratch
+// interior left in nxt is overwritten by the next real pass.
+int csim_stepper_keep_warm(csim_stepper* s, double D, double dt, double vx, double vy, double seconds) {
+    CSIM_REQUIRE(s, "null stepper");
+    CSIM_REQUIRE(seconds >= 0.0 && seconds <= 10.0, "seconds must be in [0, 10]");
+    const auto t0 = std::chrono::steady_clock::now();
+    auto elapsed = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    const int depth = fused_depth(s);
+    if (depth < 2) return CSIM_OK;
+    Phys p = make_phys(s->dx, s->dy, D, dt, vx, vy, s->contract != 0);
+    if (!s->fused_2c) p.fast_thr = 0.0;
+    int kind[4];
+    for (int k = 0; k < 4; ++k) kind[k] = s->phys[k] ? s->bc[k] : 3;
+    CSIM_HIP(hipStreamSynchronize(s->s_comm));
+    CSIM_HIP(hipStreamSynchronize(s->s_comp));
+    double last = 0.0;
+    for (int n = 0; n < 100000; ++n) {
+        const double before = elapsed();
+        if (before + 1.25 * last >= seconds) break;  // the next launch would run past the deadline
+        CSIM_HIP(launch_sweepO(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, s->cfg, kind, s->bc_value, depth, 0, s->s_comp));
+        CSIM_HIP(hipStreamSynchronize(s->s_comp));
+        last = elapsed() - before;
+    }
+    return CSIM_OK;
 }
 
 int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy, int nsteps) {

@@ -175,6 +175,13 @@ int csim_pass_schedule(int nsteps, int smallest_tile, long tile_cells, int fuse,
 /* optional, before a timed loop: the one-off rows-per-chunk trial that the first long
  * csim_stepper_run would otherwise do (option "autotune"); does not advance the field */
 int csim_stepper_tune(csim_stepper* s, double D, double dt, double vx, double vy);
+/* measurement helper: keep this GPU under the stepper's own load for about `seconds` WITHOUT advancing the field
+ * and without any communication (whole-tile launches of the multi-step sweep into the scratch buffer, like the
+ * trial launches of _tune), returning with the GPU idle not later than `seconds` after the call.  For the wait
+ * between a cross-rank barrier and a timed region (reference: the MPI_Wtime bracket of src/main.cpp:94,111 has no
+ * such wait): a GPU that idles for milliseconds leaves its sustained power state and runs the first launches of
+ * the timed region 5-15 % slower. */
+int csim_stepper_keep_warm(csim_stepper* s, double D, double dt, double vx, double vy, double seconds);
 int csim_stepper_sync(csim_stepper* s);
 int csim_stepper_minmax(csim_stepper* s, double out_min_max[2]);
 int csim_stepper_sum(csim_stepper* s, double* out);

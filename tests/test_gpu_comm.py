@@ -239,6 +239,42 @@ def test_fuzz_random_torus_cases_vs_oracle(csim):
                                                        float(np.abs(got - want)[mask].max()))
 
 
+@pytest.mark.parametrize("overlap", [3, 4, 1])
+def test_keep_warm_leaves_the_run_untouched(csim, overlap):
+    """csim_stepper_keep_warm (bench.py's wait between the cross-rank barrier and the timed region): whole-tile
+    launches into the scratch buffer between run() calls — also between a run that left faces pre-unpacked for
+    nobody and the next one — must not change a bit of what the runs produce, ghost ring included."""
+    import time
+    nx, ny = 1160, 300
+    D, vx, vy, dt = 0.05, 0.5, -0.25, 0.1
+    sides, bc = (1, 1, 0, 0), "ddnp"
+    rng = np.random.default_rng(41)
+    u0 = np.zeros((ny + 2, nx + 2))
+    u0[1:-1, 1:-1] = rng.standard_normal((ny, nx))
+    u0[0, :], u0[-1, :] = 0.5, -0.25
+    codes = csim.bc_codes(bc)
+    want = torus_oracle(u0, 1.0, 1.0, D, vx, vy, dt, 6 + 13 + 1, sides, codes)
+    st = csim.Stepper(self_neighbor_decomp(csim, nx, ny, sides), 1.0, 1.0, codes)
+    st.comm_init(csim.comm_unique_id())
+    st.set_option("overlap", overlap)
+    st.set_option("fuse", 6)
+    st.upload(u0)
+    t0 = time.perf_counter()
+    st.keep_warm(D, dt, vx, vy, 0.02)
+    took = time.perf_counter() - t0
+    assert took < 0.05          # returns by the deadline (plus call overhead), GPU idle
+    st.run(D, dt, vx, vy, 6)
+    st.keep_warm(D, dt, vx, vy, 0.005)
+    st.run(D, dt, vx, vy, 13)
+    st.keep_warm(D, dt, vx, vy, 0.0)
+    st.run(D, dt, vx, vy, 1)
+    got = st.download()
+    st.close()
+    mask = np.ones(got.shape, bool)
+    mask[[0, 0, -1, -1], [0, -1, 0, -1]] = False
+    assert np.array_equal(got[mask], want[mask])
+
+
 def test_exchange_halos_alone(csim):
     """reference tests/simulation/unit/test_halo.cpp:36-56 restated: after exchange_halos every
     ghost face on a neighbour side holds the neighbour's edge cells, physical sides untouched."""
