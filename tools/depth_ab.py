@@ -16,7 +16,7 @@ csim.set_device(0)
 for (nx, ny) in [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]] or [(16384, 16384), (8192, 8192), (4096, 8192)]:
     res = {}
     for rnd in range(3):
-        for depth in (3, 4, 5, 6, 7):
+        for depth in (2, 3, 4, 5, 6, 7):
             st = csim.Stepper.single(nx, ny, 1.0, 1.0, csim.bc_codes("dddd"))
             st.set_option("fuse", depth)
             st.init_gaussian()
