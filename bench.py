@@ -251,6 +251,13 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
 
+    # stdout carries ONE JSON line (rank 0) and nothing else: the native libraries print banners straight to file
+    # descriptor 1 (RCCL's version block, gloo's connection note), so descriptor 1 points at stderr until the line
+    # is written
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
+
     # CPU baseline first: it forks mpirun, which must happen before this process touches the GPU
     cpu = None
     if world == 1 and not self_torus and not args.no_cpu_baseline:
@@ -601,6 +608,8 @@ def main():
         }
         if cpu is not None:
             line["cpu_baseline"] = cpu
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
         print(json.dumps(line), flush=True)
 
 

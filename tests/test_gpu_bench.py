@@ -19,6 +19,8 @@ def run_bench(extra, env=None):
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
+    # ONE JSON line and nothing else on stdout (RCCL / gloo banners belong on stderr)
+    assert [ln for ln in p.stdout.splitlines() if ln.strip()] == lines, p.stdout[:2000]
     return json.loads(lines[0])
 
 
@@ -70,6 +72,7 @@ def test_bench_two_ranks_host_staged_fallback():
     assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
     lines = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]
     assert len(lines) == 1 and not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]
+    assert outs[0][0].strip() == lines[0] and outs[1][0].strip() == ""   # nothing but the one line on any rank's stdout
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["scaling"] == "strong"
     assert r["config"]["halo_transport"].startswith("gloo")
