@@ -4,6 +4,8 @@ step — edge-pack kernel, grouped ncclSend/ncclRecv on the second stream, event
 in the ghost fill, overlap on/off — through real RCCL calls.  (The reference itself never
 wraps; the torus is only the cheapest way to exercise the exchange on one device.
 Multi-rank decomposition logic is covered on CPU by tests/test_multirank_gloo.py.)"""
+import os
+
 import numpy as np
 import pytest
 
@@ -207,7 +209,7 @@ def test_fuzz_random_torus_cases_vs_oracle(csim):
     """80 seeded random cases of the RCCL path on the self-linked torus: tile shape, which side pairs are linked,
     the BC of the physical sides, physics, step count cut into two run() calls, pass depth, exchange schedule —
     the full array (ghost ring included, corners excepted: SURVEY Q7) against the oracle's torus."""
-    rng = np.random.default_rng(777)
+    rng = np.random.default_rng(int(os.environ.get("CSIM_FUZZ_SEED", "777")))   # (other seeds: extended soak runs)
     for case in range(80):
         nx, ny = int(rng.integers(8, 700)), int(rng.integers(8, 260))
         sides = [(1, 1, 1, 1), (1, 1, 0, 0), (0, 0, 1, 1)][int(rng.integers(0, 3))]

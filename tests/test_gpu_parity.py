@@ -231,7 +231,7 @@ def test_fuzz_random_shapes_options_and_physics_vs_oracle(csim):
     power-of-two / general: the three division modes), velocity signs, step count, pass depth, chunk height,
     block map — each compared with the oracle bit for bit, ghost ring included.  The fixed lists above aim at
     known seams; this one is for the shapes nobody thought of."""
-    rng = np.random.default_rng(20260704)
+    rng = np.random.default_rng(int(os.environ.get("CSIM_FUZZ_SEED", "20260704")))   # (other seeds: extended soak runs)
     spacings = [(1.0, 1.0), (0.5, 0.25), (2.0, 0.5), (0.7, 1.3), (1.0, 0.3)]
     for case in range(1500):
         big = case % 10 == 0
