@@ -143,6 +143,35 @@ def test_torus_mixed_physical_and_linked_sides_depth6(csim, sides, bc, overlap):
     assert np.array_equal(got[mask], want[mask]), float(np.abs(got - want)[mask].max())
 
 
+@pytest.mark.parametrize("sides,bc", [((1, 1, 0, 0), "ddnp"), ((0, 0, 1, 1), "pndd"), ((1, 1, 0, 0), "ddnn"), ((0, 0, 1, 1), "nndd"),
+                                      ((1, 1, 1, 1), "dddd")])
+@pytest.mark.parametrize("overlap", [3, 4, 1])
+def test_mixed_sides_depths_7_6_5_on_one_stepper(csim, sides, bc, overlap):
+    """the comm-stream chain (faces -> halo cells, ghost ring, extension of the physical edges over the halo,
+    corners) with linked sides next to physical Neumann / Periodic / Dirichlet sides, passes of depth 7, 6 and 5 on
+    the same stepper: the full array incl. the ghost ring against the oracle's torus."""
+    nx, ny, steps = 1160, 300, 18
+    D, vx, vy, dt = 0.05, -0.5, 0.25, 0.1
+    rng = np.random.default_rng(29)
+    u0 = np.zeros((ny + 2, nx + 2))
+    u0[1:-1, 1:-1] = rng.standard_normal((ny, nx))
+    u0[0, :], u0[-1, :], u0[:, 0], u0[:, -1] = 0.5, -0.25, 0.125, -1.5
+    codes = csim.bc_codes(bc)
+    want = torus_oracle(u0, 1.0, 1.0, D, vx, vy, dt, steps, sides, codes)
+    st = csim.Stepper(self_neighbor_decomp(csim, nx, ny, sides), 1.0, 1.0, codes)
+    st.comm_init(csim.comm_unique_id())
+    st.set_option("overlap", overlap)
+    st.upload(u0)
+    for depth, n in ((7, 7), (6, 6), (5, 5)):
+        st.set_option("fuse", depth)
+        st.run(D, dt, vx, vy, n)
+    got = st.download()
+    st.close()
+    mask = np.ones(got.shape, bool)
+    mask[[0, 0, -1, -1], [0, -1, 0, -1]] = False
+    assert np.array_equal(got[mask], want[mask]), float(np.abs(got - want)[mask].max())
+
+
 @pytest.mark.parametrize("direct", [1, 0])
 @pytest.mark.parametrize("shape", [(1161, 301, 6), (897, 130, 7), (300, 171, 5), (2049, 64, 4), (127, 40, 3), (64, 515, 2)])
 @pytest.mark.parametrize("sides,bc", [((1, 1, 1, 1), "dddd"), ((1, 1, 0, 0), "ddpn"), ((0, 0, 1, 1), "pndd")])
