@@ -140,6 +140,8 @@ def lib() -> C.CDLL:
         "csim_stepper_keep_warm": (i, [vp, d, d, d, d, d]),
         "csim_pass_schedule": (i, [i, i, C.c_long, i, ip, i, C.POINTER(C.c_long)]),
         "csim_stepper_sync": (i, [vp]),
+        "csim_stepper_checksum": (i, [vp, C.POINTER(C.c_ulonglong)]),
+        "csim_stepper_comm_share": (i, [vp, vp]),
         "csim_stepper_minmax": (i, [vp, dp]),
         "csim_stepper_sum": (i, [vp, dp]),
         "csim_stepper_set_option": (i, [vp, C.c_char_p, C.c_long]),
@@ -294,6 +296,18 @@ class Field:
         return o.value
 
 
+def checksum_host(interior: np.ndarray, x_offset=0, y_offset=0, nx_global=None) -> int:
+    """numpy restatement of csim_stepper_checksum for an (ny, nx) interior block (the checker's side)"""
+    a = np.ascontiguousarray(interior, dtype=np.float64)
+    ny, nx = a.shape
+    nxg = nx if nx_global is None else nx_global
+    g = (np.arange(ny, dtype=np.uint64)[:, None] + np.uint64(y_offset)) * np.uint64(nxg) + \
+        (np.arange(nx, dtype=np.uint64)[None, :] + np.uint64(x_offset))
+    with np.errstate(over="ignore"):
+        w = np.uint64(0x9E3779B97F4A7C15) + np.uint64(2) * g
+        return int((a.view(np.uint64) * w).sum(dtype=np.uint64))
+
+
 def apply_boundary(f: Field, bc, is_physical=(1, 1, 1, 1), value=0.0):
     _ck(lib().csim_apply_boundary(f._h, _i4(bc), _i4(is_physical), value))
 
@@ -341,6 +355,16 @@ class Stepper:
     def comm_init(self, unique_id: bytes):
         buf = C.create_string_buffer(unique_id, UNIQUE_ID_BYTES)
         _ck(lib().csim_stepper_comm_init(self._h, buf, UNIQUE_ID_BYTES))
+
+    def comm_share(self, owner: "Stepper"):
+        """borrow another stepper's RCCL communicator (same rank; the owner must outlive this one)"""
+        _ck(lib().csim_stepper_comm_share(self._h, owner._h))
+
+    def checksum(self) -> int:
+        """position-weighted 64-bit checksum of the local interior (csim_stepper_checksum)"""
+        v = C.c_ulonglong(0)
+        _ck(lib().csim_stepper_checksum(self._h, C.byref(v)))
+        return v.value
 
     def upload(self, host: np.ndarray):
         assert host.shape == (self.ny + 2, self.nx + 2)

@@ -148,6 +148,9 @@ struct csim_stepper {
     hipStream_t s_comp = nullptr, s_comm = nullptr;
     hipEvent_t ev_edge = nullptr, ev_recv = nullptr, ev_ready = nullptr;
     ncclComm_t comm = nullptr;
+    bool comm_borrowed = false;  // csim_stepper_comm_share: another stepper owns `comm`
+    long sync_timeout_ms = 0;    // > 0: csim_stepper_sync gives up after that long (CSIM_ERR_TIMEOUT)
+    bool stall_armed = false;    // option "test_stall": the comm stream is parked on a value only the host will write
     bool multi = false;       // has at least one neighbour
     bool halo_fresh = false;  // recv[] holds the neighbours' edge lines of `cur`
     bool edge_async = false;  // ... and the exchange that delivers them was posted on s_comm (ev_recv marks its end)
@@ -604,7 +607,7 @@ int csim_stepper_destroy(csim_stepper* s) {
     if (s->ev_snap_src) (void)hipEventDestroy(s->ev_snap_src);
     if (s->ev_snap_copied) (void)hipEventDestroy(s->ev_snap_copied);
     if (s->s_io) (void)hipStreamDestroy(s->s_io);
-    if (s->comm) (void)ncclCommDestroy(s->comm);
+    if (s->comm && !s->comm_borrowed) (void)ncclCommDestroy(s->comm);
     for (hipEvent_t ev : s->ev_pool) (void)hipEventDestroy(ev);
     for (int k = 0; k < 4; ++k) {
         if (s->send[k]) (void)hipFree(s->send[k]);
@@ -646,6 +649,20 @@ int csim_stepper_comm_init(csim_stepper* s, const void* id, size_t nbytes) {
     ncclUniqueId u;
     std::memcpy(&u, id, sizeof(u));
     CSIM_NCCL(ncclCommInitRank(&s->comm, s->dec.size, u, s->dec.rank));
+    return CSIM_OK;
+}
+
+// Several steppers of one rank on one communicator (e.g. small parity cases run beside the production tile:
+// building a communicator costs ~1 s at 8 ranks).  `s` borrows `owner`'s communicator and never destroys it;
+// `owner` must outlive `s`.  The steppers must not have exchanges in flight at the same time (RCCL matches the
+// messages of a rank pair in posting order): sync one before running the other.
+int csim_stepper_comm_share(csim_stepper* s, csim_stepper* owner) {
+    CSIM_REQUIRE(s && owner && s != owner, "bad argument");
+    if (s->comm) return fail(CSIM_ERR_STATE, "communicator already initialised");
+    if (!owner->comm) return fail(CSIM_ERR_STATE, "owner has no communicator: csim_stepper_comm_init first");
+    CSIM_REQUIRE(s->dec.size == owner->dec.size && s->dec.rank == owner->dec.rank, "steppers of different ranks / world sizes");
+    s->comm = owner->comm;
+    s->comm_borrowed = true;
     return CSIM_OK;
 }
 
@@ -736,7 +753,7 @@ int csim_stepper_init_gaussian(csim_stepper* s, double A, double sigma_frac, dou
 }
 
 // one grouped RCCL exchange (replaces the <= 8 MPI requests + MPI_Waitall of reference src/halo.cpp:28-46):
-// depth 1 = the staged edge lines of the four sides, depth 2..6 = the deep faces of all eight
+// depth 1 = the staged edge lines of the four sides, depth 2..7 = the deep faces of all eight
 // directions (diagonal ranks are direct xGMI peers too), in the order csim_exchange_plan fixes.
 static int post_plan(csim_stepper* s, int depth, hipStream_t st) {
     if (!s->comm) return fail(CSIM_ERR_STATE, "halo exchange needs csim_stepper_comm_init first");
@@ -747,11 +764,22 @@ static int post_plan(csim_stepper* s, int depth, hipStream_t st) {
     double* const* sbuf = depth == 1 ? s->send : s->send2;
     double* const* rbuf = depth == 1 ? s->recv : s->recv2;
     CSIM_NCCL(ncclGroupStart());
-    for (int k = 0; k < ns; ++k)
-        CSIM_NCCL(ncclSend(sbuf[sends[k].dir], static_cast<size_t>(sends[k].count), ncclDouble, sends[k].peer, s->comm, st));
-    for (int k = 0; k < nr; ++k)
-        CSIM_NCCL(ncclRecv(rbuf[recvs[k].dir], static_cast<size_t>(recvs[k].count), ncclDouble, recvs[k].peer, s->comm, st));
-    CSIM_NCCL(ncclGroupEnd());
+    // A failed send/recv must not leave the group open (every later RCCL call of this thread would be
+    // swallowed into it): stop posting, close the group, then report the first failure.
+    ncclResult_t bad = ncclSuccess;
+    const char* what = "";
+    for (int k = 0; k < ns && bad == ncclSuccess; ++k) {
+        bad = ncclSend(sbuf[sends[k].dir], static_cast<size_t>(sends[k].count), ncclDouble, sends[k].peer, s->comm, st);
+        what = "ncclSend";
+    }
+    for (int k = 0; k < nr && bad == ncclSuccess; ++k) {
+        bad = ncclRecv(rbuf[recvs[k].dir], static_cast<size_t>(recvs[k].count), ncclDouble, recvs[k].peer, s->comm, st);
+        what = "ncclRecv";
+    }
+    const ncclResult_t end = ncclGroupEnd();
+    if (bad != ncclSuccess)
+        return fail(CSIM_ERR_RCCL, std::string(what) + " (halo exchange, depth " + std::to_string(depth) + "): " + ncclGetErrorString(bad));
+    if (end != ncclSuccess) return fail(CSIM_ERR_RCCL, std::string("ncclGroupEnd: ") + ncclGetErrorString(end));
     return CSIM_OK;
 }
 static int post_exchange(csim_stepper* s, hipStream_t st) { return post_plan(s, 1, st); }
@@ -1025,7 +1053,7 @@ static int pass_single(csim_stepper* s, const Phys& p, const GhostArgs& g) {
     return CSIM_OK;
 }
 
-// T = 2..6 reference steps in one HBM pass.  Several ranks: faces of depth T (8 directions) are
+// T = 2..7 reference steps in one HBM pass.  Several ranks: faces of depth T (8 directions) are
 // staged in recv2[]; when the next pass is fused too (with `next_T` steps), the frame tiles are
 // computed first and the comm stream packs and exchanges their depth-next_T faces while the bulk
 // of the sweep is still running.
@@ -1426,6 +1454,11 @@ int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy,
     } else if (s->multi && !s->comm) {
         return fail(CSIM_ERR_STATE, "multi-rank stepper needs csim_stepper_comm_init before run");
     }
+    // Invariant every schedule relies on: a run starts with no deep faces staged and nothing pre-unpacked (each
+    // run's last pass has no successor, so it ends that way; external mode stages faces explicitly per call).
+    if (!s->external && (s->faces_depth != 0 || s->pre_unpacked))
+        return fail(CSIM_ERR_STATE, "internal: csim_stepper_run entered with faces of a fused pass in flight "
+                                    "(an earlier call failed half-way?): upload or re-initialise the field");
     Phys p = make_phys(s->dx, s->dy, D, dt, vx, vy, s->contract != 0);
     if (!s->fused_2c) p.fast_thr = 0.0;
     s->fused_2c_active = p.fast_thr > 0.0 && p.div_mode != 3;
@@ -1460,10 +1493,60 @@ int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy,
     return prof_close(s);
 }
 
+// Wait for both streams.  With an RCCL communicator the wait polls instead of blocking, so that an asynchronous
+// communicator error (a peer that died, a failed transport: ncclCommGetAsyncError) ends it with CSIM_ERR_RCCL
+// instead of a silent hang on a stream nobody will ever complete — the reference's MPI_Waitall
+// (src/halo.cpp:46) would abort the job through the MPI error handler.  Option "sync_timeout_ms" > 0 bounds the
+// wait (CSIM_ERR_TIMEOUT; the streams stay as they are).
+static int wait_stream(csim_stepper* s, hipStream_t st, const std::chrono::steady_clock::time_point& t0) {
+    if (!s->comm && s->sync_timeout_ms <= 0 && !s->stall_armed) {
+        CSIM_HIP(hipStreamSynchronize(st));
+        return CSIM_OK;
+    }
+    for (unsigned long spin = 0;; ++spin) {
+        const hipError_t q = hipStreamQuery(st);
+        if (q == hipSuccess) return CSIM_OK;
+        if (q != hipErrorNotReady) return fail(CSIM_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(q));
+        (void)hipGetLastError();  // hipErrorNotReady is sticky in the last-error slot
+        if ((spin & 63) == 63) {
+            if (s->comm) {
+                ncclResult_t async = ncclSuccess;
+                const ncclResult_t r = ncclCommGetAsyncError(s->comm, &async);
+                if (r != ncclSuccess || (async != ncclSuccess && async != ncclInProgress))
+                    return fail(CSIM_ERR_RCCL, std::string("halo exchange failed asynchronously: ") +
+                                                   ncclGetErrorString(r != ncclSuccess ? r : async));
+            }
+            if (s->sync_timeout_ms > 0) {
+                const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                if (ms > static_cast<double>(s->sync_timeout_ms))
+                    return fail(CSIM_ERR_TIMEOUT, "csim_stepper_sync: streams still busy after " +
+                                                      std::to_string(s->sync_timeout_ms) + " ms (option sync_timeout_ms)");
+            }
+        }
+    }
+}
+
 int csim_stepper_sync(csim_stepper* s) {
     CSIM_REQUIRE(s, "null stepper");
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = wait_stream(s, s->s_comp, t0);
+    if (rc) return rc;
+    return wait_stream(s, s->s_comm, t0);
+}
+
+// Position-weighted 64-bit checksum of the local interior (k_checksum): the per-rank values of a decomposition
+// add up modulo 2^64 to the checksum of the same global field on one rank.
+int csim_stepper_checksum(csim_stepper* s, unsigned long long* out) {
+    CSIM_REQUIRE(s && out, "null argument");
+    const long nxg = s->dec.nx_global > 0 ? s->dec.nx_global : s->nx;
+    CSIM_HIP(launch_checksum(s->cur, s->nx, s->ny, s->pitch, s->dec.x_offset, s->dec.y_offset, nxg, s->scratch, s->s_comp));
+    const int nb = reduce_blocks(s->ny);
+    std::vector<unsigned long long> h(static_cast<size_t>(nb));
+    CSIM_HIP(hipMemcpyAsync(h.data(), s->scratch, sizeof(unsigned long long) * nb, hipMemcpyDeviceToHost, s->s_comp));
     CSIM_HIP(hipStreamSynchronize(s->s_comp));
-    CSIM_HIP(hipStreamSynchronize(s->s_comm));
+    unsigned long long acc = 0;
+    for (int k = 0; k < nb; ++k) acc += h[static_cast<size_t>(k)];
+    *out = acc;
     return CSIM_OK;
 }
 
@@ -1503,6 +1586,9 @@ int csim_stepper_set_option(csim_stepper* s, const char* key, long value) {
         s->cfg.tuned_rows = 0;
     } else if (k == "overlap") {
         CSIM_REQUIRE(value >= 0 && value <= 5 && value != 2, "overlap must be 0, 1, 3, 4 or 5");
+        // the schedules hand state to each other only through "nothing in flight": every csim_stepper_run ends that way
+        if (!s->external && (s->faces_depth != 0 || s->pre_unpacked))
+            return fail(CSIM_ERR_STATE, "internal: exchange schedule changed with faces of a fused pass in flight");
         if (value == 3 && s->multi && !s->frame_flag)
             return fail(CSIM_ERR_STATE, "overlap 3 needs hipStreamWaitValue64 / signal memory, which this device or runtime refused");
         s->overlap = static_cast<int>(value);
@@ -1540,6 +1626,25 @@ int csim_stepper_set_option(csim_stepper* s, const char* key, long value) {
         s->cfg.tuned_rows = 0;
     } else if (k == "tuned_rows" || k == "last_rows") {  // read back through csim_stepper_get_option
         return fail(CSIM_ERR_ARG, k + " is read-only");
+    } else if (k == "sync_timeout_ms") {
+        CSIM_REQUIRE(value >= 0, "sync_timeout_ms must be >= 0");
+        s->sync_timeout_ms = value;
+    } else if (k == "test_stall") {
+        // Test hook for the stall handling of callers (bench.py's watchdog, csim_stepper_sync's timeout): 1 parks the
+        // comm stream on a value of the signal word that no kernel ever publishes — exactly what a lost flag or a
+        // dead peer looks like from the host —, 0 releases it from the host and restores the word.
+        CSIM_REQUIRE(value == 0 || value == 1, "test_stall must be 0 or 1");
+        if (!s->frame_flag) return fail(CSIM_ERR_STATE, "test_stall needs a multi-rank stepper with signal memory");
+        constexpr unsigned long long NEVER = 1ull << 62;
+        if (value == 1 && !s->stall_armed) {
+            CSIM_HIP(hipStreamWaitValue64(s->s_comm, s->frame_flag, NEVER, hipStreamWaitValueGte, ~0ull));
+            s->stall_armed = true;
+        } else if (value == 0 && s->stall_armed) {
+            __atomic_store_n(s->frame_flag, NEVER, __ATOMIC_SEQ_CST);
+            CSIM_HIP(hipStreamSynchronize(s->s_comm));
+            __atomic_store_n(s->frame_flag, s->pass_no, __ATOMIC_SEQ_CST);
+            s->stall_armed = false;
+        }
     } else if (k == "profile") {
         CSIM_REQUIRE(value >= 0 && value <= 1024, "profile must be 0..1024");
         s->profile = static_cast<int>(value);
@@ -1570,6 +1675,9 @@ int csim_stepper_get_option(const csim_stepper* s, const char* key, long* value)
     else if (k == "contract") *value = s->contract;
     else if (k == "autotune") *value = s->autotune;
     else if (k == "profile") *value = s->profile;
+    else if (k == "sync_timeout_ms") *value = s->sync_timeout_ms;
+    else if (k == "test_stall") *value = s->stall_armed;
+    else if (k == "faces_in_flight") *value = s->faces_depth != 0 || s->pre_unpacked;
     else return fail(CSIM_ERR_ARG, "unknown option: " + k);
     return CSIM_OK;
 }

@@ -114,7 +114,7 @@ inline int pref_fuse(long tile_cells) {
     return tile_cells >= BIG_TILE_CELLS ? 7 : (tile_cells > 0 && tile_cells < SMALL_TILE_CELLS) ? 4 : 6;
 }
 constexpr int GHOST_EXTRA = 6;    // device-only ghost layers beyond the reference's one (= MAX_FUSE-1)
-// faces of depth H = 2..6 (8 directions: L R B T BL BR TL TR; nullptr = no neighbour there);
+// faces of depth H = 2..7 (8 directions: L R B T BL BR TL TR; nullptr = no neighbour there);
 // sizes H*(ny+2) (L,R), H*(nx+2) (B,T), H*H (corners)
 hipError_t launch_halo2_pack(const double* f, int nx, int ny, int pitch, int depth,
                              double* const send[8], hipStream_t st);
@@ -158,6 +158,9 @@ hipError_t launch_minmax(const double* f, int nx, int ny, int pitch, double* scr
 hipError_t launch_sum(const double* f, int nx, int ny, int pitch, double* scratch, hipStream_t st);
 hipError_t launch_linf(const double* a, const double* b, int nx, int ny, int pitch, double* scratch,
                        hipStream_t st);
+// position-weighted 64-bit checksum of the interior (k_checksum): min(ny, REDUCE_BLOCKS) u64 partials in `scratch`
+hipError_t launch_checksum(const double* f, int nx, int ny, int pitch, long x_off, long y_off, long nx_global,
+                           double* scratch, hipStream_t st);
 
 }  // namespace csim
 

@@ -9,10 +9,10 @@
 //   * temporal blocking: up to seven time levels stay in registers per pass (k_sweepO_dpp, the
 //     default), which divides the HBM traffic per step by as much and leaves the kernel bound by the
 //     reference's own fp64 add/mul stream.
-// Kernels, in file order: k_sweep_dpp (1 step/pass), k_sweepO_dpp (2-6 steps/pass, overlapped
+// Kernels, in file order: k_sweep_dpp (1 step/pass), k_sweepO_dpp (2-7 steps/pass, overlapped
 // strips, DEFAULT), k_sweep_lds (the LDS-staged design, measured alternative), k_sweep_naive
 // (strawman), then the small kernels (ghost fill / extend, edge and face packing,
-// reference-granularity operators, reductions).  Superseded families: tools/proto/legacy_sweeps.hip.
+// reference-granularity operators, reductions, the bit-identity checksum).
 //
 // Arithmetic follows the reference's association order exactly (reference
 // src/diffusion.cpp:9-16, src/advection.cpp:13-33) and this file is compiled with
@@ -1102,15 +1102,15 @@ __global__ __launch_bounds__(256) void k_pack(const double* __restrict__ in, int
     }
 }
 
-// ---- depth-2 faces for the two-steps-per-pass sweep on several ranks -------------------------
+// ---- deep faces for the multi-step sweep on several ranks (depth H = 2..7) --------------------
 // Directions: 0 left, 1 right, 2 bottom, 3 top, 4 bottom-left, 5 bottom-right, 6 top-left,
-// 7 top-right.  Faces hold the two outermost interior columns (2 x ny), rows (2 x (nx+2),
-// ghost columns included so Periodic ghosts travel with them) or the 2 x 2 corner block.
+// 7 top-right.  Faces hold the H outermost interior columns (H x (ny+2)), rows (H x (nx+2); ghost
+// entries included so Periodic ghosts travel with them) or the H x H corner block.
 struct Halo2Ptrs {
     double* p[8];
 };
 
-// H = face depth (= time steps of the fused pass that will consume the faces, 2..4).
+// H = face depth (= time steps of the fused pass that will consume the faces, 2..7).
 // Column faces span rows 0..ny+1 and row faces columns 0..nx+1, i.e. they carry the sender's
 // ghost entries along, so that Periodic (never rewritten) ghosts reach the neighbour.
 __global__ __launch_bounds__(256) void k_halo2_pack(const double* __restrict__ f, int nx, int ny,
@@ -1253,6 +1253,31 @@ __global__ __launch_bounds__(256) void k_reduce(const double* __restrict__ a,
         partial[blockIdx.x] = x0;
         partial[REDUCE_BLOCKS + blockIdx.x] = x1;
     }
+}
+
+// Position-weighted 64-bit checksum of the interior: sum over cells of bits(u) * (K + 2 g) mod 2^64, g = the cell's
+// GLOBAL linear index.  Every multiplier is odd, so any change of any cell changes the sum, and because the
+// weights follow the global position the per-rank sums of a decomposed field add up (mod 2^64) to the checksum
+// of the same field held by one rank — the bit-identity check a multi-GPU run can carry in one number.
+__global__ __launch_bounds__(256) void k_checksum(const double* __restrict__ f, int nx, int ny, int pitch,
+                                                  long x_off, long y_off, long nx_global,
+                                                  unsigned long long* __restrict__ partial) {
+    __shared__ unsigned long long sh[4];
+    unsigned long long acc = 0;
+    for (int j = 1 + blockIdx.x; j <= ny; j += gridDim.x) {
+        const unsigned long long row = static_cast<unsigned long long>(y_off + j - 1) * static_cast<unsigned long long>(nx_global) +
+                                       static_cast<unsigned long long>(x_off);
+        for (int i = 1 + threadIdx.x; i <= nx; i += 256) {
+            const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(f[at(i, j, pitch)]));
+            acc += bits * (0x9E3779B97F4A7C15ull + 2ull * (row + static_cast<unsigned long long>(i - 1)));
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) sh[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
 // ============================================================================================
@@ -1437,6 +1462,13 @@ hipError_t launch_linf(const double* a, const double* b, int nx, int ny, int pit
                        hipStream_t st) {
     hipLaunchKernelGGL(k_reduce<2>, dim3(reduce_grid(ny)), dim3(256), 0, st, a, b, 1, nx, 1, ny, pitch,
                        scratch);
+    return hipGetLastError();
+}
+
+hipError_t launch_checksum(const double* f, int nx, int ny, int pitch, long x_off, long y_off, long nx_global,
+                           double* scratch, hipStream_t st) {
+    hipLaunchKernelGGL(k_checksum, dim3(reduce_grid(ny)), dim3(256), 0, st, f, nx, ny, pitch, x_off, y_off, nx_global,
+                       reinterpret_cast<unsigned long long*>(scratch));
     return hipGetLastError();
 }
 

@@ -38,7 +38,8 @@ enum {
     CSIM_ERR_HIP = 2,         /* a HIP runtime call failed, or no device */
     CSIM_ERR_RCCL = 3,        /* an RCCL call failed */
     CSIM_ERR_STATE = 4,       /* call sequence error (e.g. multi-rank run before comm init) */
-    CSIM_ERR_UNSUPPORTED = 5
+    CSIM_ERR_UNSUPPORTED = 5,
+    CSIM_ERR_TIMEOUT = 6      /* csim_stepper_sync with option "sync_timeout_ms": the streams did not drain in time */
 };
 
 /* reference include/boundary.hpp:5  enum class BCType { Dirichlet, Neumann, Periodic } */
@@ -128,6 +129,10 @@ int csim_stepper_destroy(csim_stepper* s);
  * (MPI_Bcast, torch.distributed store, file), then every rank calls csim_stepper_comm_init. */
 int csim_comm_unique_id(void* id, size_t nbytes);
 int csim_stepper_comm_init(csim_stepper* s, const void* id, size_t nbytes);
+/* a second stepper of the SAME rank borrows `owner`'s communicator (small parity cases beside the production tile
+ * without paying for another communicator); owner must outlive s, and only one of them may have an exchange in
+ * flight at a time (sync one before running the other) */
+int csim_stepper_comm_share(csim_stepper* s, csim_stepper* owner);
 int csim_stepper_upload(csim_stepper* s, const double* host_with_ghosts);   /* local tile */
 int csim_stepper_download(csim_stepper* s, double* host_with_ghosts);
 int csim_stepper_download_interior(csim_stepper* s, double* host_ny_by_nx);
@@ -161,7 +166,7 @@ int csim_stepper_faces_unpack(csim_stepper* s, int depth, const double* const ho
 /* reference src/halo.cpp:6-50  exchange_halos(u, dec, comm) on the current field */
 int csim_stepper_exchange_halos(csim_stepper* s);
 /* nsteps x { exchange_halos; apply_boundary; fused sweep; swap }, enqueued without host syncs;
- * internally up to 6 steps share one pass over HBM; the last pass of a call also leaves the ghost
+ * internally up to 7 steps share one pass over HBM; the last pass of a call also leaves the ghost
  * ring the reference would (halos / boundary values of the state before the last step) */
 int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy, int nsteps);
 /* The pass schedule of csim_stepper_run(nsteps) as pure host arithmetic: depths[k] = time steps the k-th
@@ -182,7 +187,14 @@ int csim_stepper_tune(csim_stepper* s, double D, double dt, double vx, double vy
  * such wait): a GPU that idles for milliseconds leaves its sustained power state and runs the first launches of
  * the timed region 5-15 % slower. */
 int csim_stepper_keep_warm(csim_stepper* s, double D, double dt, double vx, double vy, double seconds);
+/* waits for everything enqueued.  With an RCCL communicator the wait polls ncclCommGetAsyncError, so a failed
+ * exchange returns CSIM_ERR_RCCL instead of hanging (the reference's MPI_Waitall, src/halo.cpp:46, aborts through
+ * the MPI error handler); option "sync_timeout_ms" > 0 bounds the wait (CSIM_ERR_TIMEOUT). */
 int csim_stepper_sync(csim_stepper* s);
+/* bit-identity in one number: sum over the local interior of bits(u) * (0x9E3779B97F4A7C15 + 2 g) mod 2^64, g = the
+ * cell's global linear index (y_offset + j) * nx_global + x_offset + i.  The values of all ranks of a decomposition
+ * add up (mod 2^64) to the checksum of the same global field on one rank, whatever the process grid. */
+int csim_stepper_checksum(csim_stepper* s, unsigned long long* out);
 int csim_stepper_minmax(csim_stepper* s, double out_min_max[2]);
 int csim_stepper_sum(csim_stepper* s, double* out);
 /* tuning / measurement knobs; unknown keys give CSIM_ERR_ARG.  Results never depend on them, with ONE
@@ -197,7 +209,8 @@ int csim_stepper_sum(csim_stepper* s, double* out);
  *                    E - 2c and N - 2c as one fma(-2, c, .) each — 2c is exact, so the result is the reference's —
  *                    and every tile screens the values it loads: if one is so large that some 2c of the pass
  *                    could overflow (or is NaN / Inf), the tile is recomputed with the reference's own operation
- *                    sequence.  14 instead of 15 fp64 operations per cell.  "fused_2c_active" (read-only): whether
+ *                    sequence (bit-identical for every non-NaN cell, the same cells NaN; the reference does not define NaN
+ *                    payloads).  14 instead of 15 fp64 operations per cell.  "fused_2c_active" (read-only): whether
  *                    the last run's parameters allowed it (growth bound per step, see make_phys)
  *   "fuse"           time steps per HBM pass: -1 auto (the cheapest split of a run into passes of 2..7 steps, e.g.
  *                    1000 = 166 x 6 + 4, 20 = 7 + 7 + 6), 0/1 off, 2..7 balanced passes of at most that depth
@@ -217,6 +230,9 @@ int csim_stepper_sum(csim_stepper* s, double* out);
  *   "frame_rows"     experiment: chunk height of the frame's side strips in a multi-rank pass (0 = default, the 12-14
  *                    rows of the bottom/top bands; measured best)
  *   "external_halo"  0/1 the caller carries the faces (csim_stepper_halo_* / _faces_*)
+ *   "sync_timeout_ms" 0 (default): csim_stepper_sync waits as long as it takes; > 0: gives up with CSIM_ERR_TIMEOUT
+ *   "test_stall"     test hook: 1 parks the comm stream on a signal value nobody publishes (what a lost flag or a
+ *                    dead peer looks like from the host), 0 releases it
  *   "profile"        0 off, k >= 1: HIP events around the sweep launch(es) of every k-th pass
  *                    (csim_stepper_kernel_time)
  *   "autotune"       0/1 (default 1) with rows_per_chunk = 0: the first long run times the candidate

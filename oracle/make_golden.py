@@ -75,6 +75,16 @@ RUN_CASES = [
          dt=0.1, steps=11, bc="dnpd", ic="random", seed=14, ranks=[1, 2, 4]),
     dict(name="run_fused_384x36", nx=384, ny=36, dx=1.0, dy=1.0, D=0.1, vx=-0.3, vy=0.4,
          dt=0.1, steps=8, bc="npnd", ic="random", seed=15, ranks=[1, 3]),
+    # 4 x 2 process grids (the 8-GPU topology: mid-x ranks with three side and two diagonal peers), every
+    # tile at least 7 cells deep so that fused passes of every depth run across the seams
+    dict(name="run_np8_neumann_72x40", nx=72, ny=40, dx=1.0, dy=1.0, D=0.1, vx=-0.4, vy=-0.3,
+         dt=0.2, steps=15, bc="nnnn", ic="gaussian", sigma_frac=0.08, ranks=[1, 8]),
+    dict(name="run_np8_remainder_59x37", nx=59, ny=37, dx=0.5, dy=2.0, D=0.02, vx=0.3, vy=-0.5,
+         dt=0.05, steps=10, bc="dpnd", ic="random", seed=21, ranks=[1, 2, 8]),
+    dict(name="run_np8_nonpow2_61x29", nx=61, ny=29, dx=0.7, dy=1.3, D=0.08, vx=-0.6, vy=0.9,
+         dt=0.1, steps=9, bc="npdn", ic="random", seed=22, ranks=[1, 4, 8]),
+    dict(name="run_np8_fused_520x30", nx=520, ny=30, dx=1.0, dy=1.0, D=0.05, vx=0.5, vy=0.25,
+         dt=0.1, steps=16, bc="dddd", ic="random", seed=23, ranks=[1, 8]),
 ]
 
 
@@ -221,6 +231,13 @@ def main():
     if not os.path.exists(REF_RUN):
         subprocess.run(["make", "-C", HERE], check=True)
     os.makedirs(GOLD, exist_ok=True)
+    only = [a[len("--only="):] for a in sys.argv[1:] if a.startswith("--only=")]
+    if only:  # add or refresh single run cases without touching the other fixtures
+        with tempfile.TemporaryDirectory() as tmp:
+            for c in RUN_CASES:
+                if c["name"] in only:
+                    gen_run_case(c, tmp)
+        return 0
     with tempfile.TemporaryDirectory() as tmp:
         for c in RUN_CASES:
             gen_run_case(c, tmp)

@@ -329,3 +329,103 @@ def test_multi_rank_run_needs_comm(csim):
     with pytest.raises(csim.CsimError):
         st.run(0.1, 0.1, 0.0, 0.0, 1)
     st.close()
+
+
+def CORNERLESS(ny, nx):
+    """corner ghosts are never exchanged at depth 1 (the reference leaves them undefined)"""
+    m = np.ones((ny + 2, nx + 2), bool)
+    m[[0, 0, -1, -1], [0, -1, 0, -1]] = False
+    return m
+
+
+def test_checksum_is_decomposition_invariant_and_matches_numpy(csim):
+    """csim_stepper_checksum: position-weighted sum of the interior's bit patterns; the per-tile values of any
+    decomposition add up (mod 2^64) to the checksum of the whole field — here against the numpy restatement."""
+    nx, ny = 301, 173
+    rng = np.random.default_rng(3)
+    g = rng.standard_normal((ny, nx))
+    g[5, 7], g[6, 7] = 1e-310, -0.0          # a subnormal and a negative zero: bit patterns, not values
+    want = csim.checksum_host(g)
+    u0 = np.zeros((ny + 2, nx + 2))
+    u0[1:-1, 1:-1] = g
+    st = csim.Stepper.single(nx, ny)
+    st.upload(u0)
+    assert st.checksum() == want
+    g2 = g.copy()
+    g2[100, 200], g2[100, 201] = g[100, 201], g[100, 200]   # two cells swapped: same multiset of values
+    u0[1:-1, 1:-1] = g2
+    st.upload(u0)
+    assert st.checksum() != want and st.checksum() == csim.checksum_host(g2)
+    st.close()
+    for world in (2, 6, 8):
+        total = 0
+        for r in range(world):
+            dec = csim.decomp_init(world, r, nx, ny)
+            t = np.zeros((dec.ny_local + 2, dec.nx_local + 2))
+            t[1:-1, 1:-1] = g[dec.y_offset:dec.y_offset + dec.ny_local, dec.x_offset:dec.x_offset + dec.nx_local]
+            s = csim.Stepper(dec)
+            s.upload(t)
+            part = s.checksum()
+            assert part == csim.checksum_host(t[1:-1, 1:-1], dec.x_offset, dec.y_offset, nx)
+            total = (total + part) % (1 << 64)
+            s.close()
+        assert total == want, world
+
+
+def test_sync_timeout_and_injected_stall_are_reported_not_hung(csim):
+    """A comm stream that never drains (option "test_stall": parked on a signal value nobody publishes — what a
+    lost flag or a dead peer looks like from the host) must come back from csim_stepper_sync as CSIM_ERR_TIMEOUT
+    when "sync_timeout_ms" is set, leave the stepper usable after the release, and not change any result."""
+    nx, ny, steps = 512, 256, 14
+    D, vx, vy, dt = 0.05, 0.5, -0.25, 0.1
+    rng = np.random.default_rng(23)
+    u0 = np.zeros((ny + 2, nx + 2))
+    u0[1:-1, 1:-1] = rng.standard_normal((ny, nx))
+    want = torus_oracle(u0, 1.0, 1.0, D, vx, vy, dt, steps)
+    st = csim.Stepper(self_neighbor_decomp(csim, nx, ny, (1, 1, 1, 1)), 1.0, 1.0, csim.bc_codes("dddd"))
+    st.comm_init(csim.comm_unique_id())
+    st.upload(u0)
+    st.run(D, dt, vx, vy, 7)
+    st.sync()
+    st.set_option("sync_timeout_ms", 300)
+    st.set_option("test_stall", 1)
+    with pytest.raises(csim.CsimError) as e:
+        st.sync()
+    assert e.value.code == 6 and "sync_timeout_ms" in str(e.value)
+    st.set_option("test_stall", 0)
+    st.sync()
+    st.set_option("sync_timeout_ms", 0)
+    st.run(D, dt, vx, vy, steps - 7)
+    assert np.array_equal(st.download()[CORNERLESS(ny, nx)], want[CORNERLESS(ny, nx)])
+    st.close()
+
+
+def test_borrowed_communicator_runs_a_second_stepper(csim):
+    """csim_stepper_comm_share: a small parity case beside the production tile on ONE communicator (what
+    bench.py's preflight does at N > 1), both bit-identical to the oracle, the borrower closed first."""
+    D, vx, vy, dt = 0.05, 0.5, -0.25, 0.1
+    rng = np.random.default_rng(29)
+    big = csim.Stepper(self_neighbor_decomp(csim, 1024, 512, (1, 1, 1, 1)), 1.0, 1.0, csim.bc_codes("dddd"))
+    big.comm_init(csim.comm_unique_id())
+    small = csim.Stepper(self_neighbor_decomp(csim, 96, 40, (1, 1, 1, 1)), 1.0, 1.0, csim.bc_codes("dddd"))
+    small.comm_share(big)
+    with pytest.raises(csim.CsimError):
+        small.comm_share(big)
+    fields = {}
+    for st, (nx, ny) in ((big, (1024, 512)), (small, (96, 40))):
+        u0 = np.zeros((ny + 2, nx + 2))
+        u0[1:-1, 1:-1] = rng.standard_normal((ny, nx))
+        st.upload(u0)
+        fields[st] = u0
+    for overlap in (0, 4, 3):
+        for st in (small, big):
+            st.set_option("overlap", overlap)
+            st.upload(fields[st])
+            st.run(D, dt, vx, vy, 13)
+            st.sync()   # one stepper's exchanges at a time on a shared communicator
+            m = CORNERLESS(st.ny, st.nx)
+            assert np.array_equal(st.download()[m], torus_oracle(fields[st], 1.0, 1.0, D, vx, vy, dt, 13)[m]), overlap
+    small.close()
+    big.run(D, dt, vx, vy, 2)
+    big.sync()
+    big.close()

@@ -1,14 +1,13 @@
 """N > 1 on ONE GPU: 2/3/4-rank runs of the HIP stepper, one process per rank, all on device
 0, halos carried by gloo through csim_stepper_halo_pack/_unpack (RCCL refuses two ranks on one
 device; the RCCL calls themselves are covered by tests/test_gpu_comm.py).  Checked bit-for-bit
-against the golden vectors of the reference's own `mpirun -np N` runs."""
+against the golden vectors of the reference's own `mpirun -np N` runs.  (Full-size decomposed runs and the
+4 x 2 / 3 x 2 process grids: tests/test_gpu_virtual8.py, all ranks in one process, against the oracle.)"""
 import os
-import subprocess
-import sys
 
 import pytest
 
-from test_multirank_gloo import cases_with, free_port, launch
+from test_multirank_gloo import cases_with, launch
 
 pytestmark = pytest.mark.gpu
 
@@ -31,26 +30,6 @@ def test_hip_stepper_fused_passes_multirank_one_gpu(world, depth):
     for case in cases:
         rc, out = launch(world, f"hip-external{depth}", case, timeout=600)
         assert rc == 0 and "ok=True" in out, (os.path.basename(case), out[-3000:])
-
-
-@pytest.mark.parametrize("nx,ny,bc,steps,world", [(16384, 16384, "dddd", 14, 4), (16384, 16384, "dnnd", 9, 4),
-                                                  (32768, 16384, "nnnn", 8, 4), (16384, 16384, "dddd", 8, 2)])
-def test_full_size_decomposed_runs_equal_the_single_rank_run(nx, ny, bc, steps, world):
-    """BASELINE configs[3] as a decomposed run — 16384^2 on 2 x 2 ranks (local 8192^2), all on this one GPU
-    with host-staged faces — and half of configs[4]'s grid (32768 x 16384, all-Neumann, 2 x 2: the 16384 x 8192
-    tiles of the 4 x 2 run transposed) must give, tile by tile and bit for bit, what ONE rank computes for
-    the whole grid (tests/multirank_fullsize_worker.py).  8 ranks do not fit the box's process cap; RCCL
-    between distinct GPUs is not involved (unverified on hardware)."""
-    port = str(free_port())
-    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "multirank_fullsize_worker.py")
-    procs = []
-    for r in range(world):
-        env = dict(os.environ, OMP_NUM_THREADS="1", RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
-        procs.append(subprocess.Popen([sys.executable, worker, "--nx", str(nx), "--ny", str(ny), "--steps", str(steps),
-                                       "--bc", bc], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env))
-    outs = [p.communicate(timeout=900)[0] for p in procs]
-    assert all(p.returncode == 0 for p in procs) and "ok=True" in outs[0], "\n".join(o[-1500:] for o in outs)
 
 
 def _visible_gpus():
