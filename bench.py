@@ -378,11 +378,12 @@ def main():
         os.dup2(stdout_fd, 1)
         os.write(1, (json.dumps(line) + "\n").encode())
 
-    wd = Watchdog(rank, emit)
-
-    # CPU baseline first: it forks mpirun, which must happen before this process touches the GPU
+    # CPU baseline first: it forks mpirun, which must happen before this process touches the GPU (and before the
+    # watchdog blocks SIGTERM for every thread created from here on)
     if world == 1 and not self_torus and not args.no_cpu_baseline:
         S["cpu"] = cpu_baseline()
+
+    wd = Watchdog(rank, emit)
 
     import numpy as np
     import torch  # noqa: F401  (plumbing: torch.distributed control plane; also pins ONE HIP runtime)
