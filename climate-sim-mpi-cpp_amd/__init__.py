@@ -21,7 +21,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-LIB_PATH = os.path.join(HERE, "lib", "libcsim.so")
+# CSIM_LIB: another build of the engine (A/B measurements of two kernel versions in tools/)
+LIB_PATH = os.environ.get("CSIM_LIB") or os.path.join(HERE, "lib", "libcsim.so")
 HEADER = os.path.join(ROOT, "include", "csim.h")
 
 DIRICHLET, NEUMANN, PERIODIC = 0, 1, 2

@@ -323,6 +323,67 @@ struct FinLines {
     double* line[4];  // left/right: ny entries; bottom/top: nx entries; all nullptr = off
 };
 
+// Tiles of one launch: up to four rectangular regions of (strip, chunk) tiles, numbered
+// consecutively; wavefront w of block b owns tile 4 b + w.  One region (all strips x all rows) is
+// the whole-field launch; a multi-rank pass splits the field into the FRAME (bottom band, top
+// band, left strip(s), right strip(s): thin tiles, finished early so that the faces can travel
+// while the rest computes) and the BULK (everything else).
+struct TileRegion {
+    int t_end;          // tiles [t_end of the previous region, t_end)
+    int strip0, nstrip; // strips strip0 .. strip0 + nstrip - 1
+    int j0, j1, ry;     // rows j0 .. j1 in chunks of ry
+};
+struct Tiling {
+    TileRegion r[8];
+    int nregions, ntiles;
+    // merged launch (frame + bulk in one grid): tiles [0, frame_tiles) are the frame, owned by blocks
+    // [0, frame_blocks) in plain order so that they are dispatched first and spread over all XCDs; the
+    // bulk tiles follow from tile 4 * frame_blocks on, XCD-remapped among themselves.  0 = not merged.
+    int frame_tiles, frame_blocks;
+    // TAIL region: the last tail_blocks blocks own, in plain order, the tiles of the last region(s) — the top
+    // eighth of the (bulk of the) field cut into chunks of half the height, dispatched last, so that the
+    // chip drains in half-height steps instead of idling behind the last full-height wavefronts
+    // (17 468 wavefronts are 4.26 rounds of 4096 slots on 16384^2: the partial last round was 7 % of the
+    // launch).  The main tiles before them fill their blocks exactly and are XCD-remapped.  0 = no tail.
+    int tail_blocks;
+};
+
+
+// The by-value argument block of k_sweepO_dpp (behind the two field pointers, which stay direct __restrict__
+// parameters).  Everything a wavefront needs BEFORE or DURING its march is read from the parameter as usual; what it
+// needs only rarely or only AFTER the march — the FinLines pointers, the whole FrameSync — is read from the
+// kernel-argument segment at the point of use (LateArgs), so that those ~40 scalars are not kept alive (and
+// spilled to VGPR lanes: 101 SGPR spills, 524 v_readlane/v_writelane per edge group of six in round 2) across the
+// loop that is the kernel.
+struct SweepArgs {
+    int nx, ny, pitch, nstrips, swz;
+    Tiling tl;
+    Phys p;
+    Bc2 bc;
+    FinLines fin;
+    FrameSync fs;
+};
+constexpr int SWEEP_ARGS_KERNARG_OFFSET = 16;  // two pointers precede it; alignof(SweepArgs) == 8
+
+struct LateArgs {
+    typedef const SweepArgs __attribute__((address_space(4))) * Ptr;
+    Ptr a;
+    __device__ __forceinline__ static LateArgs get() {
+        typedef const char __attribute__((address_space(4))) * Bytes;
+        LateArgs l;
+        l.a = (Ptr)((Bytes)__builtin_amdgcn_kernarg_segment_ptr() + SWEEP_ARGS_KERNARG_OFFSET);
+        return l;
+    }
+    // an opaque copy of the pointer: the loads through it stay where they are written (the scalar data cache
+    // serves them; the kernel-argument segment is a few hundred bytes)
+    __device__ __forceinline__ Ptr here() const {
+        Ptr q = a;
+        asm volatile("" : "+s"(q));
+        return q;
+    }
+    __device__ __forceinline__ double* fin_line(int side) const { return here()->fin.line[side]; }
+};
+
 template <int T>
 struct OverlapGeom {
     static constexpr int TP = 2 * ((T + 1) / 2);       // T rounded up to even
@@ -335,25 +396,59 @@ struct OverlapGeom {
 // reach 2^1023.  The march returns true if any lane saw a value that is not below the threshold (NaN and Inf
 // included) and the caller then repeats the tile with the plain form — same loads, same stores, the reference's
 // own operations.  Cost: two compares per lane and loaded row against 2 T multiplies saved.
-template <int DIV, int T, bool EDGE, int SX, int SY, bool FAST = false>
+//
+// The EDGE body (wavefronts whose strip or chunk touches a physical edge, and the frame tiles of a final pass) is
+// the interior body plus PATCHES that put the boundary rule where a level's ghost cells come out.  Every patch sits
+// in a wave-uniform branch and works on values made opaque INSIDE that branch (pin / pin2: an empty asm the value
+// passes through), so that the compiler can neither hoist the patch's moves, lane shifts and selects out of the
+// branch nor turn the branch into per-lane selects executed by every level-row — which is what it did to the
+// plain `if` blocks of round 2: 667 v_cndmask + 312 DPP moves + 524 v_readlane/v_writelane (101 spilled scalars)
+// per group of six at T = 7, 2.2 x the instructions of the interior body.  What remains in the steady state:
+//   * ghost COLUMNS (first / last strips): per level-row and side one per-lane select (Dirichlet / Periodic: the
+//     ghost keeps its value; 2 v_cndmask) or a lane shift + select (Neumann; 2 DPP + 2 v_cndmask);
+//   * ghost ROWS (physical bottom / top) only come out in the first ~2T and the last ~2T iterations of a chunk that
+//     reaches the edge: the row tests run only in groups of six that can contain one (`rows_here`), elsewhere a
+//     level-row pays one scalar branch;
+//   * the FinLines emission of a run's last pass: scalar tests at level T-1, with the four line pointers read from
+//     the kernel-argument segment where they are used (LateArgs) instead of living in scalars across the march.
+__device__ __forceinline__ void pin(double& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin2(double2& v) { asm volatile("" : "+v"(v.x), "+v"(v.y)); }
+
+// MODE: which body this instantiation is — ONE march loop each, so that every flavour is register-allocated like the
+// interior body (several bodies chained in one function grew the kernel from 124 to 179-194 VGPRs, i.e. from 4 to 2
+// wavefronts per SIMD for EVERY tile):
+//   M_FAST / M_PLAIN  interior body with / without the fused E - 2c (see FAST above)
+//   M_GENERIC         edge body with every patch behind run-time tests: tiles that can produce ghost ROWS of a
+//                     physical edge (the launcher keeps them thin: bottom / top bands) and strips that hold BOTH ghost
+//                     columns; also every edge tile of the instantiations that are not specialised (SPECIALISE_EDGES)
+//   0..6              edge body of a strip with at most ONE ghost column and no ghost rows, its patch compiled in,
+//                     straight-line like the interior body: 0 none (a final pass's frame tile that only emits
+//                     FinLines), 1 / 2 left ghost kept / Neumann, 3 / 4 right ghost kept in .x / .y, 5 / 6 right
+//                     ghost Neumann in .x / .y
+constexpr int M_FAST = -3, M_PLAIN = -2, M_GENERIC = -1;
+
+template <int DIV, int T, int MODE, int SX, int SY>
 __device__ __forceinline__ bool sweepO_march(const double* __restrict__ in, double* __restrict__ out,
                                              int nx, int ny, int pitch, int jb, int je, int g0, int lane,
-                                             int kl, int kr, const Phys& p, const Bc2& bc,
-                                             const FinLines& fin, bool fin_l, bool fin_r, bool wt) {
+                                             int kl, int kr, const Phys& p, int kb, int kt,
+                                             LateArgs late, bool fin_any, bool fin_l, bool fin_r, bool wt) {
     constexpr int TP = OverlapGeom<T>::TP;
     constexpr int STRIDE = OverlapGeom<T>::STRIDE;
+    constexpr bool EDGE = MODE >= M_GENERIC, FAST = MODE == M_FAST, GENERIC = MODE == M_GENERIC;
+    constexpr int CASE = MODE;
     // this lane's two columns, 0-based interior index (-1 = left ghost, nx = right ghost)
     const int gx = g0 + 2 * lane, gy = gx + 1;
     const ptrdiff_t xoff = LPAD + gx;
-    const int kb = bc.kind[CSIM_BOTTOM], kt = bc.kind[CSIM_TOP];  // 3 = neighbour rank: plain stencil
+    // kb / kt: kind of the bottom / top side, 3 = neighbour rank: plain stencil
     // output lanes: local columns [TP, TP + STRIDE), clipped to the interior
     const bool out_lane = 2 * lane >= TP && 2 * lane < TP + STRIDE && gx < nx;
     const int nvalid = nx - gx;
-    // lanes that hold a ghost column of a physical edge (EDGE bodies only)
+    // lanes that hold a ghost column of a physical edge (EDGE bodies only).  g0 is even, so the right ghost column
+    // (index nx) is the .x of its lane when nx is even and the .y when nx is odd: wave-uniform
     const bool ghost_ly = kl != 3 && gy == -1;
     const bool ghost_rx = kr != 3 && gx == nx, ghost_ry = kr != 3 && gy == nx;
+    const bool right_in_x = (nx & 1) == 0;
     const bool ghost_cols = kl != 3 || kr != 3;  // wave-uniform
-    const bool fin_any = fin.line[CSIM_BOTTOM] != nullptr;  // all four are set together
 
     auto load = [&](int j) {
         return *reinterpret_cast<const double2*>(in + static_cast<ptrdiff_t>(j) * pitch + xoff);
@@ -393,6 +488,10 @@ __device__ __forceinline__ bool sweepO_march(const double* __restrict__ in, doub
     // copy: it is rare and its code is three times the size.)
     auto group = [&](auto gtag, int k0) {
         constexpr int G = decltype(gtag)::value;
+        // GENERIC: can this group of six contain a ghost row of a physical edge?  Level l = 1..T-1 produces ghost row 0
+        // at iteration l + T - 2 - jb (patched from row 1 one iteration later) and ghost row ny+1 at iteration
+        // ny + l + T - 1 - jb: only in groups with  k0 <= 2T - 2 - jb  (bottom)  or  k0 + 5 >= ny + T - jb  (top)
+        const bool rows_here = GENERIC && ((kb != 3 && k0 <= 2 * T - 2 - jb) || (kt != 3 && k0 + 5 >= ny + T - jb));
 #pragma unroll
         for (int u = 0; u < 6; ++u) {
             {
@@ -406,7 +505,7 @@ __device__ __forceinline__ bool sweepO_march(const double* __restrict__ in, doub
                     const double2 n = (l == 1) ? L0[(u + 2) % 6] : L[l - 1][u % 3];
                     // The stencil is evaluated on every lane and row (branch-free, the same code as
                     // the interior body); where the result is a ghost cell of a physical edge it is
-                    // then replaced by the boundary rule in rarely taken, wave-uniform side blocks.
+                    // then replaced by the boundary rule.
                     double2 o;
                     {
                         const double Wx = shift_from_prev(c.y);
@@ -415,55 +514,92 @@ __device__ __forceinline__ bool sweepO_march(const double* __restrict__ in, doub
                         o.y = cell<DIV, SX, SY, FAST>(c.y, c.x, Ey, s.y, n.y, p);
                         if (FAST && l == 1) screen(n);
                     }
-                    if (EDGE && l < T) {
-                        const bool gb = rho == 0 && kb != 3, gt = rho == ny + 1 && kt != 3;
-                        if (gb || gt) {  // ghost ROW of this level
-                            keep_branch();
-                            const int kk = gb ? kb : kt;
-                            if (kk != CSIM_BC_NEUMANN)
-                                o = c;  // Dirichlet / Periodic ghosts keep their level-0 value (bc.value / stored)
-                            else if (gt)
-                                o = L[l][(u + 2) % 3];  // Neumann top: row ny of this level
-                            // (Neumann bottom: patched below as soon as row 1 of this level exists)
-                        } else if (ghost_cols) {  // ghost COLUMNS of this level (first / last strip)
-                            keep_branch();
+                    if (EDGE && !GENERIC && l < T) {  // the strip's one ghost column, unconditionally
+                        if (CASE == 1) o.y = ghost_ly ? c.y : o.y;
+                        if (CASE == 2) {
+                            const double nb = shift_from_next(o.x);
+                            o.y = ghost_ly ? nb : o.y;
+                        }
+                        if (CASE == 3) o.x = ghost_rx ? c.x : o.x;
+                        if (CASE == 4) o.y = ghost_ry ? c.y : o.y;
+                        if (CASE == 5) {
+                            const double pb = shift_from_prev(o.y);
+                            o.x = ghost_rx ? pb : o.x;
+                        }
+                        if (CASE == 6) o.y = ghost_ry ? o.x : o.y;
+                    }
+                    if (GENERIC && l < T) {
+                        bool ghost_row = false;
+                        if (rows_here) {
+                            const bool gb = rho == 0 && kb != 3, gt = rho == ny + 1 && kt != 3;
+                            ghost_row = gb || gt;
+                            if (ghost_row) {  // ghost ROW of this level
+                                const int kk = gb ? kb : kt;
+                                if (kk != CSIM_BC_NEUMANN) {  // Dirichlet / Periodic ghosts keep their level-0 value (bc.value / stored)
+                                    double2 t = c;
+                                    pin2(t);
+                                    o = t;
+                                } else if (gt) {  // Neumann top: row ny of this level
+                                    double2 t = L[l][(u + 2) % 3];
+                                    pin2(t);
+                                    o = t;
+                                }
+                                // (Neumann bottom: patched below as soon as row 1 of this level exists)
+                            }
+                        }
+                        if (!ghost_row && ghost_cols) {  // ghost COLUMNS of this level (first / last strip)
                             if (kl == CSIM_BC_NEUMANN) {  // left ghost (.y of its lane) := column 0 (.x of the next lane)
-                                keep_branch();
-                                const double nb = shift_from_next(o.x);
+                                double t = o.x;
+                                pin(t);
+                                const double nb = shift_from_next(t);
                                 o.y = ghost_ly ? nb : o.y;
                             } else if (kl != 3) {  // Dirichlet / Periodic: unchanged through the levels
-                                keep_branch();
-                                o.y = ghost_ly ? c.y : o.y;
+                                double t = c.y;
+                                pin(t);
+                                o.y = ghost_ly ? t : o.y;
                             }
-                            if (kr == CSIM_BC_NEUMANN) {  // right ghost := column nx-1 (.y of the previous lane, or own .x)
-                                keep_branch();
-                                const double pb = shift_from_prev(o.y);
-                                o.x = ghost_rx ? pb : o.x;
-                                o.y = ghost_ry ? o.x : o.y;
+                            if (kr == CSIM_BC_NEUMANN) {  // right ghost := column nx-1 (.y of the previous lane, or the lane's own .x)
+                                if (right_in_x) {
+                                    double t = o.y;
+                                    pin(t);
+                                    const double pb = shift_from_prev(t);
+                                    o.x = ghost_rx ? pb : o.x;
+                                } else {
+                                    double t = o.x;
+                                    pin(t);
+                                    o.y = ghost_ry ? t : o.y;
+                                }
                             } else if (kr != 3) {
-                                keep_branch();
-                                o.x = ghost_rx ? c.x : o.x;
-                                o.y = ghost_ry ? c.y : o.y;
+                                if (right_in_x) {
+                                    double t = c.x;
+                                    pin(t);
+                                    o.x = ghost_rx ? t : o.x;
+                                } else {
+                                    double t = c.y;
+                                    pin(t);
+                                    o.y = ghost_ry ? t : o.y;
+                                }
                             }
                         }
                     }
                     if (EDGE && T >= 2 && l == T - 1 && fin_any) {  // see FinLines
                         keep_branch();
                         if (rho >= jb && rho <= je) {
-                            if (fin_l && (kl != 3 ? gx == 0 : gy == -1)) fin.line[CSIM_LEFT][rho - 1] = kl != 3 ? o.x : o.y;
+                            if (fin_l && (kl != 3 ? gx == 0 : gy == -1)) late.fin_line(CSIM_LEFT)[rho - 1] = kl != 3 ? o.x : o.y;
                             if (fin_r) {
                                 const int col = kr != 3 ? nx - 1 : nx;
-                                if (gx == col) fin.line[CSIM_RIGHT][rho - 1] = o.x;
-                                if (gy == col) fin.line[CSIM_RIGHT][rho - 1] = o.y;
+                                if (gx == col) late.fin_line(CSIM_RIGHT)[rho - 1] = o.x;
+                                if (gy == col) late.fin_line(CSIM_RIGHT)[rho - 1] = o.y;
                             }
                         }
-                        if (jb == 1 && rho == (kb != 3 ? 1 : 0) && out_lane) store_pair(fin.line[CSIM_BOTTOM] + gx, o.x, o.y, nvalid);
-                        if (je == ny && rho == (kt != 3 ? ny : ny + 1) && out_lane) store_pair(fin.line[CSIM_TOP] + gx, o.x, o.y, nvalid);
+                        if (jb == 1 && rho == (kb != 3 ? 1 : 0) && out_lane) store_pair(late.fin_line(CSIM_BOTTOM) + gx, o.x, o.y, nvalid);
+                        if (je == ny && rho == (kt != 3 ? ny : ny + 1) && out_lane) store_pair(late.fin_line(CSIM_TOP) + gx, o.x, o.y, nvalid);
                     }
                     if (l < T) {
-                        if (EDGE && rho == 1 && kb == CSIM_BC_NEUMANN) {  // ghost row 0 := row 1
-                            keep_branch();
-                            L[l][(u + 2) % 3] = o;
+                        if (GENERIC && rows_here && rho == 1 && kb == CSIM_BC_NEUMANN) {  // ghost row 0 := row 1
+                            double2 t = o;
+                            pin2(t);
+                            L[l][(u + 2) % 3] = t;
                         }
                         L[l][u % 3] = o;
                     } else if (rho >= jb && rho <= je && out_lane) {
@@ -479,48 +615,31 @@ __device__ __forceinline__ bool sweepO_march(const double* __restrict__ in, doub
             }
         }
     };
+    using G2 = std::integral_constant<int, 2>;
     if (EDGE) {
-        for (int k0 = 0; k0 < niter; k0 += 6) group(std::integral_constant<int, 2>{}, k0);
+        for (int k0 = 0; k0 < niter; k0 += 6) group(G2{}, k0);
     } else {
         group(std::integral_constant<int, 0>{}, 0);
         if (niter > 6) group(std::integral_constant<int, 1>{}, 6);
-        for (int k0 = 12; k0 < niter; k0 += 6) group(std::integral_constant<int, 2>{}, k0);
+        for (int k0 = 12; k0 < niter; k0 += 6) group(G2{}, k0);
     }
     return FAST && __builtin_amdgcn_ballot_w64(big) != 0;
 }
 
-// Tiles of one launch: up to four rectangular regions of (strip, chunk) tiles, numbered
-// consecutively; wavefront w of block b owns tile 4 b + w.  One region (all strips x all rows) is
-// the whole-field launch; a multi-rank pass splits the field into the FRAME (bottom band, top
-// band, left strip(s), right strip(s): thin tiles, finished early so that the faces can travel
-// while the rest computes) and the BULK (everything else).
-struct TileRegion {
-    int t_end;          // tiles [t_end of the previous region, t_end)
-    int strip0, nstrip; // strips strip0 .. strip0 + nstrip - 1
-    int j0, j1, ry;     // rows j0 .. j1 in chunks of ry
-};
-struct Tiling {
-    TileRegion r[8];
-    int nregions, ntiles;
-    // merged launch (frame + bulk in one grid): tiles [0, frame_tiles) are the frame, owned by blocks
-    // [0, frame_blocks) in plain order so that they are dispatched first and spread over all XCDs; the
-    // bulk tiles follow from tile 4 * frame_blocks on, XCD-remapped among themselves.  0 = not merged.
-    int frame_tiles, frame_blocks;
-    // TAIL region: the last tail_blocks blocks own, in plain order, the tiles of the last region(s) — the top
-    // eighth of the (bulk of the) field cut into chunks of half the height, dispatched last, so that the
-    // chip drains in half-height steps instead of idling behind the last full-height wavefronts
-    // (17 468 wavefronts are 4.26 rounds of 4096 slots on 16384^2: the partial last round was 7 % of the
-    // launch).  The main tiles before them fill their blocks exactly and are XCD-remapped.  0 = no tail.
-    int tail_blocks;
+// Which instantiations get the straight-line edge flavours (seven more march bodies, ~13 KB of code each): the
+// arithmetic modes and depths that long runs are made of.  The others (IEEE division, contracted arithmetic, the
+// shallow depths of remainder passes) run every edge tile through the generic body, as round 2 did.
+template <int DIV, int T>
+struct SPECIALISE_EDGES {
+    static constexpr bool value = (DIV == 0 || DIV == 1) && T >= 4;
 };
 
 template <int DIV, int T, int SX, int SY>
-__global__ __launch_bounds__(256) void k_sweepO_dpp(const double* __restrict__ in,
-                                                    double* __restrict__ out, int nx, int ny,
-                                                    int pitch, int nstrips, Tiling tl, int swz,
-                                                    Phys p, Bc2 bc, FinLines fin, FrameSync fs) {
+__global__ __launch_bounds__(256) void k_sweepO_dpp(const double* __restrict__ in, double* __restrict__ out, SweepArgs a) {
     constexpr int TP = OverlapGeom<T>::TP;
     constexpr int STRIDE = OverlapGeom<T>::STRIDE;
+    const int nx = a.nx, ny = a.ny, pitch = a.pitch, nstrips = a.nstrips;
+    const LateArgs late = LateArgs::get();
     const int lane = threadIdx.x & 63;
     // readfirstlane: tells the compiler the wave index (and the strip, edge kinds and row range
     // derived from it) is wave-uniform, so those tests become scalar branches
@@ -534,22 +653,22 @@ __global__ __launch_bounds__(256) void k_sweepO_dpp(const double* __restrict__ i
     bool frame_tile = false;
     {
         const int b = blockIdx.x;
-        if (b < tl.frame_blocks) {
+        if (b < a.tl.frame_blocks) {
             tile = 4 * b + wave;
-            if (tile >= tl.frame_tiles) return;  // padding of the last frame block
+            if (tile >= a.tl.frame_tiles) return;  // padding of the last frame block
             frame_tile = true;
         } else {
-            const int lb = b - tl.frame_blocks, nb_mid = gridDim.x - tl.frame_blocks - tl.tail_blocks;
-            tile = tl.frame_tiles + (lb < nb_mid ? xcd_remap(lb, nb_mid, swz) : lb) * 4 + wave;
+            const int lb = b - a.tl.frame_blocks, nb_mid = gridDim.x - a.tl.frame_blocks - a.tl.tail_blocks;
+            tile = a.tl.frame_tiles + (lb < nb_mid ? xcd_remap(lb, nb_mid, a.swz) : lb) * 4 + wave;
         }
     }
-    if (tile >= tl.ntiles) return;  // wave-uniform
-    int t0 = 0, strip0 = tl.r[0].strip0, nstrip = tl.r[0].nstrip, j0 = tl.r[0].j0, j1 = tl.r[0].j1, ry = tl.r[0].ry;
+    if (tile >= a.tl.ntiles) return;  // wave-uniform
+    int t0 = 0, strip0 = a.tl.r[0].strip0, nstrip = a.tl.r[0].nstrip, j0 = a.tl.r[0].j0, j1 = a.tl.r[0].j1, ry = a.tl.r[0].ry;
 #pragma unroll
     for (int q = 1; q < 8; ++q)
-        if (q < tl.nregions && tile >= tl.r[q - 1].t_end) {
-            t0 = tl.r[q - 1].t_end;
-            strip0 = tl.r[q].strip0, nstrip = tl.r[q].nstrip, j0 = tl.r[q].j0, j1 = tl.r[q].j1, ry = tl.r[q].ry;
+        if (q < a.tl.nregions && tile >= a.tl.r[q - 1].t_end) {
+            t0 = a.tl.r[q - 1].t_end;
+            strip0 = a.tl.r[q].strip0, nstrip = a.tl.r[q].nstrip, j0 = a.tl.r[q].j0, j1 = a.tl.r[q].j1, ry = a.tl.r[q].ry;
         }
     const int local = tile - t0;
     const int strip = strip0 + local % nstrip;
@@ -560,30 +679,50 @@ __global__ __launch_bounds__(256) void k_sweepO_dpp(const double* __restrict__ i
     const int g0 = strip * STRIDE - TP;
     // a strip meets the left ghost column iff it is the first one; the right ghost column (index
     // nx) lies inside every strip whose 128 loaded columns reach it
-    const int kl = first ? bc.kind[CSIM_LEFT] : 3;
-    const int kr = g0 + WAVE_COLS > nx ? bc.kind[CSIM_RIGHT] : 3;
+    const int kl = first ? a.bc.kind[CSIM_LEFT] : 3;
+    const int kr = g0 + WAVE_COLS > nx ? a.bc.kind[CSIM_RIGHT] : 3;
+    const int kb = a.bc.kind[CSIM_BOTTOM], kt = a.bc.kind[CSIM_TOP];
     // on the last pass of a run the frame tiles also take the edge body: they emit the FinLines
-    const bool fin_frame = fin.line[CSIM_BOTTOM] != nullptr && (first || last || jb == 1 || je == ny);
-    const bool edge = kl != 3 || kr != 3 || (bc.kind[CSIM_BOTTOM] != 3 && jb - (T - 1) < 1) ||
-                      (bc.kind[CSIM_TOP] != 3 && je + (T - 1) > ny) || fin_frame;
-    if (frame_tile && fs.prio) __builtin_amdgcn_s_setprio(3);  // the faces wait for these: issue ahead of the co-resident bulk
-    const bool wt = frame_tile && fs.flag != nullptr && fs.fence == 0;
+    const bool fin_frame = a.fin.line[CSIM_BOTTOM] != nullptr && (first || last || jb == 1 || je == ny);
+    const bool edge = kl != 3 || kr != 3 || (kb != 3 && jb - (T - 1) < 1) || (kt != 3 && je + (T - 1) > ny) || fin_frame;
+    if (frame_tile && a.fs.prio) __builtin_amdgcn_s_setprio(3);  // the faces wait for these: issue ahead of the co-resident bulk
+    const bool signalling = frame_tile && a.fs.flag != nullptr;  // merged launch: this wavefront counts itself below
+    const bool wt = signalling && a.fs.fence == 0;
     if (edge) {
-        // The edge body carries a few scalar tests and branches per level, so its wavefronts have
-        // the longest latency per row and would finish last, leaving the rest of the chip idle
-        // (29 % of a 4096 x 8192 launch, tools/wavetrace.hip): give them issue priority.
+        // Edge wavefronts run a little longer than interior ones and would finish last, leaving the rest of the chip
+        // idle (29 % of a 4096 x 8192 launch with round 1's edge body, tools/wavetrace.hip): give them issue priority.
         __builtin_amdgcn_s_setprio(3);
-        sweepO_march<DIV, T, true, SX, SY>(in, out, nx, ny, pitch, jb, je, g0, lane, kl, kr, p, bc, fin, first, last, wt);
+        const bool rows = (kb != 3 && jb - (T - 1) < 1) || (kt != 3 && je + (T - 1) > ny);
+        int col_case = 0;
+        if (kl != 3 && kr != 3)
+            col_case = 7;
+        else if (kl != 3)
+            col_case = kl == CSIM_BC_NEUMANN ? 2 : 1;
+        else if (kr != 3)
+            col_case = (kr == CSIM_BC_NEUMANN ? 5 : 3) + (nx & 1);  // g0 is even: the right ghost column is a .x iff nx is even
+        if (!SPECIALISE_EDGES<DIV, T>::value || rows || col_case == 7) col_case = -1;
+#define CSIM_MARCH(MODE_) \
+    sweepO_march<DIV, T, MODE_, SX, SY>(in, out, nx, ny, pitch, jb, je, g0, lane, kl, kr, a.p, kb, kt, late, fin_frame, first, last, wt)
+        switch (col_case) {
+            case 0: if (SPECIALISE_EDGES<DIV, T>::value) CSIM_MARCH(0); break;
+            case 1: if (SPECIALISE_EDGES<DIV, T>::value) CSIM_MARCH(1); break;
+            case 2: if (SPECIALISE_EDGES<DIV, T>::value) CSIM_MARCH(2); break;
+            case 3: if (SPECIALISE_EDGES<DIV, T>::value) CSIM_MARCH(3); break;
+            case 4: if (SPECIALISE_EDGES<DIV, T>::value) CSIM_MARCH(4); break;
+            case 5: if (SPECIALISE_EDGES<DIV, T>::value) CSIM_MARCH(5); break;
+            case 6: if (SPECIALISE_EDGES<DIV, T>::value) CSIM_MARCH(6); break;
+            default: CSIM_MARCH(M_GENERIC); break;
+        }
     } else {
         bool redo = true;
-        if (DIV != 3 && p.fast_thr > 0.0)
-            redo = sweepO_march<DIV, T, false, SX, SY, true>(in, out, nx, ny, pitch, jb, je, g0, lane, kl, kr, p, bc, fin, false, false, wt);
+        if (DIV != 3 && a.p.fast_thr > 0.0) redo = CSIM_MARCH(M_FAST);
         if (redo) {
             keep_branch();
-            sweepO_march<DIV, T, false, SX, SY>(in, out, nx, ny, pitch, jb, je, g0, lane, kl, kr, p, bc, fin, false, false, wt);
+            CSIM_MARCH(M_PLAIN);
         }
     }
-    if (frame_tile && fs.flag) {
+#undef CSIM_MARCH
+    if (signalling) {
         // Merged launch: the comm stream is parked on `flag` (hipStreamWaitValue64) and goes on to pack and
         // send the next pass's faces as soon as EVERY frame tile is in memory — while this very kernel is
         // still sweeping the bulk.  The consumers are later kernels on another stream and may run on any XCD,
@@ -593,6 +732,14 @@ __global__ __launch_bounds__(256) void k_sweepO_dpp(const double* __restrict__ i
         // output lines of the whole bulk each time: measured +40 us per 165 us pass; kept as fence = 1.)  The
         // wavefront that completes the count re-arms the counter and publishes the pass number (system scope:
         // the waiting side reads it through the command processor).
+        // Everything from here on is read from the kernel-argument segment NOW (LateArgs): nothing of FrameSync was
+        // alive during the march.
+        const LateArgs::Ptr ka = late.here();
+        FrameSync fs;
+        fs.counter = ka->fs.counter, fs.flag = ka->fs.flag, fs.pass = ka->fs.pass, fs.nframe = ka->fs.nframe;
+        fs.fence = ka->fs.fence, fs.face_depth = ka->fs.face_depth;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) fs.face[d] = ka->fs.face[d];
         if (fs.fence == 0)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (fs.fence == 0 && fs.face_depth > 0) {
@@ -607,12 +754,12 @@ __global__ __launch_bounds__(256) void k_sweepO_dpp(const double* __restrict__ i
             const bool rows_near = jb <= H || je >= ny - H + 1;              // wave-uniform
             const bool cols_near = g0 + TP < H || g0 + TP + STRIDE > nx - H;  // wave-uniform
             if (rows_near || cols_near) {
-                const int j0 = jb == 1 ? 0 : jb, j1 = je == ny ? ny + 1 : je;
+                const int jf0 = jb == 1 ? 0 : jb, jf1 = je == ny ? ny + 1 : je;
                 auto ldf = [&](const double* q) {
                     return __longlong_as_double(static_cast<long long>(__hip_atomic_load(
                         reinterpret_cast<const unsigned long long*>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
                 };
-                for (int rho = j0; rho <= j1; ++rho) {
+                for (int rho = jf0; rho <= jf1; ++rho) {
                     if (!out_lane) continue;
                     const double* src = out + static_cast<ptrdiff_t>(rho) * pitch + LPAD + gx;  // cell (gx + 1, rho)
                     face_store_cell(fs, gx + 1, rho, ldf(src), nx, ny);
@@ -630,6 +777,15 @@ __global__ __launch_bounds__(256) void k_sweepO_dpp(const double* __restrict__ i
             __threadfence();
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // experiment only: plain stores drained, NOT written back
+        // Ordering (ISA level; no C++ happens-before is claimed): every store of this wavefront that a consumer may
+        // read — tile results and face copies — is an agent-scope write-through store (global_store ... sc1), and the
+        // s_waitcnt vmcnt(0) above returns only once each of them has been acknowledged by memory.  The counter
+        // increment below is therefore issued after the data is globally visible; it can be relaxed, because the only
+        // thing ordered after it is the flag store of the LAST arriver, and that wavefront's own data was drained by
+        // its own s_waitcnt before its own increment — the increments of the others precede it in the counter's
+        // modification order, each issued after that wavefront's drain.  The flag itself is a system-scope release
+        // store; the waiting side is the command processor (hipStreamWaitValue64), and every kernel launched behind the
+        // wait begins with the usual acquire (L2 invalidate / write-back state of a kernel boundary).
         if (lane == 0) {
             const unsigned done = atomicAdd(fs.counter, 1u);
             if (done == fs.nframe - 1) {
@@ -712,7 +868,19 @@ hipError_t sweepO_div(const double* in, double* out, int nx, int ny, int pitch, 
     };
     int tail_tiles = 0;
     if (part == 0 || ((part == 1 || part == 3) && !split)) {
-        tail_tiles = add_rows(0, nstrips, 1, ny, ry);
+        // Physical bottom / top edges: the rows whose chunks can produce ghost ROWS of the intermediate levels (the
+        // first and last T-1) go into thin bands of their own, so that only those few short tiles run the generic
+        // edge body and every other tile of the first / last strips a straight-line column flavour (sweepO_march).
+        // The bands come last in the tile order, with the tail region: they are the shortest tiles of the launch.
+        int hb = T - 1;
+        hb += (6 - (hb + 2 * (T - 1)) % 6) % 6;
+        const bool bands = SPECIALISE_EDGES<DIV, T>::value && ny >= 2 * hb + 6;
+        const bool band_b = bands && bc.kind[CSIM_BOTTOM] != 3, band_t = bands && bc.kind[CSIM_TOP] != 3;
+        tail_tiles = add_rows(0, nstrips, band_b ? hb + 1 : 1, band_t ? ny - hb : ny, ry);
+        const int before = tl.ntiles;
+        if (band_b) add(0, nstrips, 1, hb, hb);
+        if (band_t) add(0, nstrips, ny - hb + 1, ny, hb);
+        tail_tiles += tl.ntiles - before;
     } else if (part == 1 || part == 3) {
         add(0, nstrips, 1, hf, hf);
         add(0, nstrips, ny - hf + 1, ny, hf);
@@ -746,9 +914,15 @@ hipError_t sweepO_div(const double* in, double* out, int nx, int ny, int pitch, 
     const dim3 grid(nblocks), block(256);
     const int sw = cfg.xcd_swizzle;
     const int sign = (p.vx >= 0.0 ? 2 : 0) + (p.vy >= 0.0 ? 1 : 0);
-#define CSIM_LAUNCH_O(SXV, SYV)                                                                        \
-    hipLaunchKernelGGL((k_sweepO_dpp<DIV, T, SXV, SYV>), grid, block, cfg.lds_bytes, st, in, out, nx, ny, pitch, \
-                       nstrips, tl, sw, p, bc, fin, fs)
+    SweepArgs ka;
+    ka.nx = nx, ka.ny = ny, ka.pitch = pitch, ka.nstrips = nstrips, ka.swz = sw;
+    ka.tl = tl, ka.p = p, ka.bc = bc, ka.fin = fin, ka.fs = fs;
+#define CSIM_LAUNCH_O(SXV, SYV) \
+    hipLaunchKernelGGL((k_sweepO_dpp<DIV, T, SXV, SYV>), grid, block, cfg.lds_bytes, st, in, out, ka)
+#ifdef CSIM_ISA_PROBE
+    (void)sign;
+    CSIM_LAUNCH_O(1, 1);
+#else
     if (DIV == 3) {  // coefficient form: the upwind directions are folded into the coefficients
         CSIM_LAUNCH_O(1, 1);
     } else {
@@ -759,6 +933,7 @@ hipError_t sweepO_div(const double* in, double* out, int nx, int ny, int pitch, 
             default: CSIM_LAUNCH_O(0, 0); break;
         }
     }
+#endif
 #undef CSIM_LAUNCH_O
     return hipGetLastError();
 }
@@ -767,12 +942,16 @@ template <int T>
 hipError_t sweepO_T(const double* in, double* out, int nx, int ny, int pitch, const Phys& p,
                            const SweepCfg& cfg, const Bc2& bc, const FinLines& fin, int part, hipStream_t st,
                            const FrameSync& fs) {
+#ifdef CSIM_ISA_PROBE  // tools: only the instantiation bench.py runs (dx = dy = 1, vx, vy >= 0), for a readable listing
+    return sweepO_div<0, T>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st, fs);
+#else
     switch (p.div_mode) {
         case 0: return sweepO_div<0, T>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st, fs);
         case 1: return sweepO_div<1, T>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st, fs);
         case 3: return sweepO_div<3, T>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st, fs);
         default: return sweepO_div<2, T>(in, out, nx, ny, pitch, p, cfg, bc, fin, part, st, fs);
     }
+#endif
 }
 
 

@@ -112,7 +112,16 @@ def main():
         ins, lps = loops(body)
         tot = collections.Counter(classify(mn, t) for mn, t in ins)
         print("   whole kernel: " + "  ".join(f"{k}={tot[k]}" for k in order if tot[k]))
+        # one line per top-level loop: the widest extent of each header, loops nested in a reported one dropped
+        widest = {}
         for tgt, a, b in lps:
+            if tgt not in widest or b > widest[tgt][2]:
+                widest[tgt] = (tgt, a, b)
+        tops = []
+        for tgt, a, b in sorted(widest.values(), key=lambda t: (t[1], -t[2])):
+            if not any(a >= ta and b <= tb for _, ta, tb in tops):
+                tops.append((tgt, a, b))
+        for tgt, a, b in tops:
             c = collections.Counter(classify(mn, t) for mn, t in ins[a:b + 1])
             if c["fp64"] < args.min_fp64:
                 continue
