@@ -483,10 +483,10 @@ def main():
 
     # exchange schedules of this run, the conservative one (nothing overlapped, no flag, no second launch) FIRST
     SCHED_NAMES = {0: "overlap-0 exchange not overlapped",
-                   4: "overlap-4 bulk launch first hiding this pass's exchange, then the frame launch",
+                   4: "overlap-4 bulk launch first hiding this pass's exchange, then the frame launch (what 5 selects)",
                    1: "overlap-1 frame launch first, next pass's exchange under the bulk launch",
                    3: "overlap-3 frame and bulk in one launch, exchange released by an in-kernel flag",
-                   5: "overlap-5 default: bulk-first on runs of < 16 passes, else frame and bulk in one launch"}
+                   5: "overlap-5 default: bulk launch first hiding this pass's exchange, then the frame launch (stream relay)"}
     if not rccl:
         schedules = [None]
     elif args.no_overlap:
@@ -494,7 +494,7 @@ def main():
     elif args.overlap_mode >= 0:
         schedules = [0, args.overlap_mode] if args.overlap_mode != 0 else [0]
     else:
-        schedules = [0, 4, 1, 3, 5]
+        schedules = [0, 5, 1, 3]   # (4 is what 5 selects since round 3)
 
     def set_schedule(ov, stepper=None):
         if ov is not None:
@@ -696,6 +696,7 @@ def main():
         if done:
             break
     S["tuned_rows"] = st.get_option("tuned_rows") or (args.rows_per_chunk or "heuristic")
+    S["tuned_rows_by_depth"] = {str(T): st.get_option(f"tuned_rows_{T}") for T in (4, 5, 6, 7)}
 
     if len(schedules) == 1:
         wd.arm(args.phase_timeout + expected_seconds(args.repeats), "timed regions")
@@ -923,6 +924,7 @@ def build_line(S):
             "relative_mass_drift": S["mass_drift"],
             "untimed_clock_ramp_steps": S["ramp_steps"],
             "rows_per_chunk": S["tuned_rows"],
+            "rows_per_chunk_by_pass_depth": S.get("tuned_rows_by_depth"),
             "rows_per_chunk_last_launch": last_rows,
             "per_rank": rep.get("per_rank"),
             "scaling_note": None if world == 1 else "N > 1 over real xGMI was never timed by the builder "

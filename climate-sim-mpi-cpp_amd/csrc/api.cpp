@@ -146,6 +146,13 @@ struct csim_stepper {
     double* recv[4]{nullptr, nullptr, nullptr, nullptr};
     double* fin[4]{nullptr, nullptr, nullptr, nullptr};  // FinLines of the last fused pass of a run (all sides)
     hipStream_t s_comp = nullptr, s_comm = nullptr;
+    // Relay (bulk-first passes): the two streams swap roles every pass — the stream that carried a pass's exchange and
+    // frame launch also takes the NEXT pass's bulk launch — so `tail` names the stream on which the current field
+    // state is ordered.  Every entry point that is not a relay pass settles it back onto s_comp first (settle()).
+    // On multi-rank steppers both streams have the same (high) priority: they carry the same kinds of work in turn.
+    hipStream_t tail = nullptr;
+    hipEvent_t ev_tail = nullptr;
+    int relay = 1;
     hipEvent_t ev_edge = nullptr, ev_recv = nullptr, ev_ready = nullptr;
     ncclComm_t comm = nullptr;
     bool comm_borrowed = false;  // csim_stepper_comm_share: another stepper owns `comm`
@@ -186,7 +193,7 @@ struct csim_stepper {
     int overlap = 5;        // 0: exchange serial; 1: frame launch, then bulk launch hiding the NEXT pass's exchange;
                             // 3: frame and bulk in ONE launch (needs signal memory, else as 1);
                             // 4: bulk launch first, hiding THIS pass's exchange, then the frame (pass_fused_bulk_first);
-                            // 5 (default): 4 on runs of fewer than SHORT_RUN_PASSES passes, 3 otherwise
+                            // 5 (default): as 4 (until round 3: 4 on runs of fewer than 16 passes, 3 otherwise)
     bool ring_ok = false;      // single rank without a Neumann side: the ghost ring (Dirichlet value / untouched
                                // Periodic ghosts) is constant and both buffers already hold it — no more ghost fills
     bool pre_unpacked = false; // the comm stream already unpacked the faces in recv2[] and filled the ghosts
@@ -200,6 +207,12 @@ struct csim_stepper {
     unsigned long prof_counter = 0;
     int autotune = 1;     // pick rows_per_chunk (when 0 = auto) by timing trial launches on this GPU
     bool tuned = false;
+    int tuned_T[MAX_FUSE + 1]{};  // chunk height found by the trial for passes of that depth (0 = not tried: cfg.tuned_rows re-snapped)
+    void forget_tuning() {
+        tuned = false;
+        cfg.tuned_rows = 0;
+        for (int& t : tuned_T) t = 0;
+    }
     std::vector<hipEvent_t> ev_pool;  // start/stop pairs around sweep launches
     std::vector<int> ev_steps;        // time steps covered by each timed launch
     std::vector<long> ev_count;       // launches bracketed by each pair (see prof_begin: runs of equal launches)
@@ -216,6 +229,23 @@ struct csim_stepper {
 
 static size_t face_doubles(int d, int H, int nx, int ny);
 size_t csim_stepper::face_len(int d, int H) const { return face_doubles(d, H, nx, ny); }
+
+// the field state back onto the compute stream (see csim_stepper::tail)
+static int settle(csim_stepper* s) {
+    if (s->tail == nullptr || s->tail == s->s_comp) {
+        s->tail = s->s_comp;
+        return CSIM_OK;
+    }
+    CSIM_HIP(hipEventRecord(s->ev_tail, s->tail));
+    CSIM_HIP(hipStreamWaitEvent(s->s_comp, s->ev_tail, 0));
+    s->tail = s->s_comp;
+    return CSIM_OK;
+}
+#define CSIM_SETTLE(s_)            \
+    do {                           \
+        int rc_ = settle(s_);      \
+        if (rc_) return rc_;       \
+    } while (0)
 
 extern "C" {
 
@@ -516,7 +546,7 @@ int csim_stepper_create(const csim_decomp* dec, double dx, double dy, const int 
         ok(hipMalloc(reinterpret_cast<void**>(&s->buf[1]), s->bytes())) &&
         ok(hipMemset(s->buf[0], 0, s->bytes())) && ok(hipMemset(s->buf[1], 0, s->bytes())) &&
         ok(hipMalloc(reinterpret_cast<void**>(&s->scratch), sizeof(double) * 2 * REDUCE_BLOCKS)) &&
-        ok(hipStreamCreateWithFlags(&s->s_comp, hipStreamNonBlocking)) &&
+        ok(hipEventCreateWithFlags(&s->ev_tail, hipEventDisableTiming)) &&
         ok(hipEventCreateWithFlags(&s->ev_ready, hipEventDisableTiming)) &&
         ok(hipEventCreateWithFlags(&s->ev_edge, hipEventDisableTiming)) &&
         ok(hipEventCreateWithFlags(&s->ev_recv, hipEventDisableTiming));
@@ -559,7 +589,10 @@ int csim_stepper_create(const csim_decomp* dec, double dx, double dy, const int 
         // bulk sweep that is hiding them
         int lo = 0, hi = 0;  // numerically lower = higher priority
         ok(hipDeviceGetStreamPriorityRange(&lo, &hi)) &&
-            ok(hipStreamCreateWithPriority(&s->s_comm, hipStreamNonBlocking, hi));
+            ok(hipStreamCreateWithPriority(&s->s_comm, hipStreamNonBlocking, hi)) &&
+            (s->multi ? ok(hipStreamCreateWithPriority(&s->s_comp, hipStreamNonBlocking, hi))
+                      : ok(hipStreamCreateWithFlags(&s->s_comp, hipStreamNonBlocking)));
+        s->tail = s->s_comp;
     }
     if (e == hipSuccess) {
         ok(hipEventCreateWithFlags(&s->ev_edge2, hipEventDisableTiming)) &&
@@ -627,6 +660,7 @@ int csim_stepper_destroy(csim_stepper* s) {
     if (s->s_comp) (void)hipStreamDestroy(s->s_comp);
     if (s->s_comm) (void)hipStreamDestroy(s->s_comm);
     if (s->ev_ready) (void)hipEventDestroy(s->ev_ready);
+    if (s->ev_tail) (void)hipEventDestroy(s->ev_tail);
     if (s->buf[0]) (void)hipFree(s->buf[0]);
     if (s->buf[1]) (void)hipFree(s->buf[1]);
     if (s->scratch) (void)hipFree(s->scratch);
@@ -668,6 +702,7 @@ int csim_stepper_comm_share(csim_stepper* s, csim_stepper* owner) {
 
 int csim_stepper_upload(csim_stepper* s, const double* host) {
     CSIM_REQUIRE(s && host, "null argument");
+    CSIM_SETTLE(s);
     CSIM_HIP(hipStreamSynchronize(s->s_comp));
     CSIM_HIP(hipStreamSynchronize(s->s_comm));
     int rc = upload_2d(s->cur, s->nx, s->ny, s->pitch, host);
@@ -687,12 +722,14 @@ int csim_stepper_upload(csim_stepper* s, const double* host) {
 
 int csim_stepper_download(csim_stepper* s, double* host) {
     CSIM_REQUIRE(s && host, "null argument");
+    CSIM_SETTLE(s);
     CSIM_HIP(hipStreamSynchronize(s->s_comp));
     return download_2d(s->cur, s->nx, s->ny, s->pitch, host);
 }
 
 int csim_stepper_download_interior(csim_stepper* s, double* host) {
     CSIM_REQUIRE(s && host, "null argument");
+    CSIM_SETTLE(s);
     CSIM_HIP(hipStreamSynchronize(s->s_comp));
     return download_interior_2d(s->cur, s->nx, s->ny, s->pitch, host);
 }
@@ -705,6 +742,7 @@ int csim_stepper_download_interior(csim_stepper* s, double* host) {
 // _begin).  Layout: ny_local x nx_local, row-major — what write_field_netcdf packs.
 int csim_stepper_snapshot_begin(csim_stepper* s) {
     CSIM_REQUIRE(s, "null stepper");
+    CSIM_SETTLE(s);
     const size_t bytes = sizeof(double) * static_cast<size_t>(s->nx) * s->ny;
     // each piece is created once; a failed allocation is reported and retried by the next call
     if (!s->s_io) CSIM_HIP(hipStreamCreateWithFlags(&s->s_io, hipStreamNonBlocking));
@@ -738,6 +776,7 @@ int csim_stepper_snapshot_wait(csim_stepper* s, const double** host_interior) {
 int csim_stepper_init_gaussian(csim_stepper* s, double A, double sigma_frac, double xc_frac,
                                double yc_frac) {
     CSIM_REQUIRE(s, "null stepper");
+    CSIM_SETTLE(s);
     CSIM_HIP(hipStreamSynchronize(s->s_comm));
     CSIM_HIP(hipMemsetAsync(s->base(s->cur), 0, s->bytes(), s->s_comp));
     CSIM_HIP(launch_gaussian(s->cur, s->nx, s->ny, s->pitch, s->dec.x_offset, s->dec.y_offset,
@@ -821,6 +860,7 @@ static bool ring_is_static(const csim_stepper* s) {
 // staging buffers the next step's ghost fill reads.
 int csim_stepper_halo_pack(csim_stepper* s, double* const host_send[4]) {
     CSIM_REQUIRE(s && host_send, "null argument");
+    CSIM_SETTLE(s);
     if (!s->multi) return CSIM_OK;
     CSIM_HIP(launch_pack(s->cur, s->nx, s->ny, s->pitch, s->send, s->s_comp));
     for (int k = 0; k < 4; ++k) {
@@ -874,6 +914,7 @@ int csim_stepper_faces_neighbors(const csim_stepper* s, int depth, int peers[8],
 
 int csim_stepper_faces_pack(csim_stepper* s, int depth, double* const host_send[8]) {
     CSIM_REQUIRE(s && host_send, "null argument");
+    CSIM_SETTLE(s);
     CSIM_REQUIRE(depth_ok(s, depth), "face depth must be 2..7 and fit the tile");
     if (!s->multi) return CSIM_OK;
     CSIM_HIP(launch_halo2_pack(s->cur, s->nx, s->ny, s->pitch, depth, s->send2, s->s_comp));
@@ -904,6 +945,7 @@ int csim_stepper_faces_unpack(csim_stepper* s, int depth, const double* const ho
 
 int csim_stepper_exchange_halos(csim_stepper* s) {
     CSIM_REQUIRE(s, "null stepper");
+    CSIM_SETTLE(s);
     if (!s->multi) return CSIM_OK;
     int rc = refresh_halos(s);
     if (rc) return rc;
@@ -970,7 +1012,8 @@ static int prof_close(csim_stepper* s) {
     return prof_stop(s, s->prof_open_slot, s->s_comp);
 }
 
-static int prof_begin(csim_stepper* s, int steps) {
+static int prof_begin(csim_stepper* s, int steps, hipStream_t st = nullptr) {
+    if (!st) st = s->s_comp;
     constexpr size_t POOL = 2048;
     if (s->profile == 1 && !s->multi) {
         // Single rank, every pass timed: ONE bracket per run of equal launches instead of one per launch.  An
@@ -1003,12 +1046,12 @@ static int prof_begin(csim_stepper* s, int steps) {
         int rc = prof_fold(s);
         if (rc) return rc;
     }
-    return prof_start(s, steps, s->s_comp, &s->prof_slot);
+    return prof_start(s, steps, st, &s->prof_slot);
 }
 
-static int prof_end(csim_stepper* s) {
+static int prof_end(csim_stepper* s, hipStream_t st = nullptr) {
     if (!s->prof_active) return CSIM_OK;
-    int rc = prof_stop(s, s->prof_slot, s->s_comp);
+    int rc = prof_stop(s, s->prof_slot, st ? st : s->s_comp);
     s->prof_active = false;
     return rc;
 }
@@ -1016,6 +1059,7 @@ static int prof_end(csim_stepper* s) {
 
 // ONE reference step: exchange_halos + apply_boundary + fused sweep + swap
 static int pass_single(csim_stepper* s, const Phys& p, const GhostArgs& g) {
+    CSIM_SETTLE(s);
     const bool rccl = s->multi && !s->external;
     if (rccl) {
         if (!s->halo_fresh) {
@@ -1062,6 +1106,7 @@ static hipError_t launch_fused(csim_stepper* s, const Phys& p, const int kind[4]
                                const FrameSync* sync = nullptr) {
     SweepCfg cfg = s->cfg;
     if (lds_bytes > 0) cfg.lds_bytes = lds_bytes;
+    if (T >= 2 && T <= MAX_FUSE && s->tuned_T[T] > 0) cfg.tuned_rows = s->tuned_T[T];  // this depth had its own trial
     cfg.rows_used = &s->last_rows;
     return launch_sweepO(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, cfg, kind, s->bc_value, T, part, st,
                          final_pass ? s->fin : nullptr, sync);
@@ -1089,28 +1134,47 @@ static int pass_fused_bulk_first(csim_stepper* s, const Phys& p, int T, bool fin
     GhostArgs g = ghost_args(s);
     for (int k = 0; k < 4; ++k) g.recv[k] = nullptr;  // neighbour sides come from the deep faces
     s->pre_unpacked = false;
-    // everything enqueued so far on the compute stream produced `cur` (and the partner buffer's ring)
-    CSIM_HIP(hipEventRecord(s->ev_ready, s->s_comp));
-    CSIM_HIP(hipStreamWaitEvent(s->s_comm, s->ev_ready, 0));
-    int rc = prof_begin(s, T);
+    // Relay (option "relay", default on): X = the stream the field state is ordered on carries the bulk; Y, the other
+    // one, carries the exchange chain and the frame launch — and, in the next pass, the bulk, which then follows the
+    // frame launch on the SAME stream without an event in between.  The one cross-stream wait per pass that remains
+    // on the way of data (Y's chain waits for X's state) sits under the bulk.  Without the relay the frame launch waits
+    // for the chain through an event (~12 us from the record to the launch it releases) and the next pass's bulk
+    // follows the frame through another record / wait pair (~8 us): 20 of the ~205 us of a 7-step pass on the 8-GPU
+    // tile (profiles/r03_timeline_torus20.txt).
+    if (!s->relay) CSIM_SETTLE(s);
+    hipStream_t X = s->tail ? s->tail : s->s_comp;
+    hipStream_t Y = X == s->s_comp ? s->s_comm : s->s_comp;
+    // everything enqueued so far on X produced `cur` (and the partner buffer's ring)
+    CSIM_HIP(hipEventRecord(s->ev_ready, X));
+    CSIM_HIP(hipStreamWaitEvent(Y, s->ev_ready, 0));
+    int rc = prof_begin(s, T, X);
     if (rc) return rc;
     // the bulk goes out first: the GPU starts on it while the host is still enqueuing the exchange
-    CSIM_HIP(launch_fused(s, p, kind, T, 2, s->s_comp));  // nothing to launch on tiles that are all frame
+    CSIM_HIP(launch_fused(s, p, kind, T, 2, X));  // nothing to launch on tiles that are all frame
+    if (s->relay) CSIM_HIP(hipEventRecord(s->ev_edge2, X));  // the bulk's end, for whatever follows the frame on Y
     long comm_slot = -1;
-    rc = prof_start(s, csim_stepper::PROF_COMM, s->s_comm, &comm_slot);
+    rc = prof_start(s, csim_stepper::PROF_COMM, Y, &comm_slot);
     if (rc) return rc;
-    CSIM_HIP(launch_halo2_pack(s->cur, s->nx, s->ny, s->pitch, T, s->send2, s->s_comm));
-    rc = post_exchange2(s, T, s->s_comm);
+    CSIM_HIP(launch_halo2_pack(s->cur, s->nx, s->ny, s->pitch, T, s->send2, Y));
+    rc = post_exchange2(s, T, Y);
     if (rc) return rc;
-    CSIM_HIP(launch_halo2_unpack(s->cur, s->nx, s->ny, s->pitch, T, s->recv2, s->s_comm));
-    CSIM_HIP(launch_ghost_fill(s->cur, s->nxt, s->nx, s->ny, s->pitch, g, s->s_comm, T));
-    rc = prof_stop(s, comm_slot, s->s_comm);
+    CSIM_HIP(launch_halo2_unpack(s->cur, s->nx, s->ny, s->pitch, T, s->recv2, Y));
+    CSIM_HIP(launch_ghost_fill(s->cur, s->nxt, s->nx, s->ny, s->pitch, g, Y, T));
+    rc = prof_stop(s, comm_slot, Y);
     if (rc) return rc;
-    CSIM_HIP(hipEventRecord(s->ev_recv2, s->s_comm));
-    CSIM_HIP(hipStreamWaitEvent(s->s_comp, s->ev_recv2, 0));
-    CSIM_HIP(launch_fused(s, p, kind, T, 1, s->s_comp, final_pass));
-    rc = prof_end(s);
+    hipStream_t F = Y;  // the frame launch follows the chain on its own stream
+    if (!s->relay) {
+        CSIM_HIP(hipEventRecord(s->ev_recv2, Y));
+        CSIM_HIP(hipStreamWaitEvent(X, s->ev_recv2, 0));
+        F = X;
+    }
+    CSIM_HIP(launch_fused(s, p, kind, T, 1, F, final_pass));
+    rc = prof_end(s, F);
     if (rc) return rc;
+    if (s->relay) {
+        CSIM_HIP(hipStreamWaitEvent(Y, s->ev_edge2, 0));  // the field is complete on Y once the bulk is done too
+        s->tail = Y;
+    }
     std::swap(s->cur, s->nxt);
     s->halo_fresh = false;
     s->faces_depth = 0;
@@ -1120,7 +1184,7 @@ static int pass_fused_bulk_first(csim_stepper* s, const Phys& p, int T, bool fin
             gf.recv[k] = s->phys[k] ? nullptr : s->fin[k];
             gf.adj[k] = s->phys[k] ? s->fin[k] : nullptr;
         }
-        CSIM_HIP(launch_ghost_fill(s->cur, s->nxt, s->nx, s->ny, s->pitch, gf, s->s_comp));
+        CSIM_HIP(launch_ghost_fill(s->cur, s->nxt, s->nx, s->ny, s->pitch, gf, s->tail));
     }
     return CSIM_OK;
 }
@@ -1129,6 +1193,7 @@ static int pass_fused(csim_stepper* s, const Phys& p, int T, int next_T, bool fi
     const bool rccl = s->multi && !s->external;
     if (rccl && s->bulk_first_run && s->faces_depth == 0)
         return pass_fused_bulk_first(s, p, T, final_pass);
+    CSIM_SETTLE(s);
     int kind[4];
     for (int k = 0; k < 4; ++k) kind[k] = s->phys[k] ? s->bc[k] : 3;
     GhostArgs g = ghost_args(s);
@@ -1226,8 +1291,8 @@ static int pass_fused(csim_stepper* s, const Phys& p, int T, int next_T, bool fi
 // its own tile once: cur -> nxt launches WITHOUT a swap, i.e. the field is not advanced and the
 // scratch interior written to nxt is overwritten by the next real pass.  Results never depend on
 // the choice.  Ranks tune independently (no communication involved).
-static int tune_rows(csim_stepper* s, const Phys& p, int T) {
-    s->tuned = true;
+static int tune_rows(csim_stepper* s, const Phys& p, int T, bool preferred_depth = true) {
+    if (preferred_depth) s->tuned = true;
     // small tiles: a launch takes a few tens of microseconds whatever the chunking, the trial
     // would cost more than it can win
     if (static_cast<long>(s->nx) * s->ny < (1L << 22)) return CSIM_OK;
@@ -1251,10 +1316,13 @@ static int tune_rows(csim_stepper* s, const Phys& p, int T) {
     const hipEvent_t e0 = ev.a, e1 = ev.b;
     CSIM_HIP(hipStreamSynchronize(s->s_comp));
     SweepCfg cfg = s->cfg;
+    // what a pass of this stepper launches with the chunk height under trial: the whole tile on one rank, the BULK of
+    // the tile (everything but the thin frame tiles, whose height is fixed) on a rank with neighbours
+    const int part = s->multi ? 2 : 0;
     auto trial = [&](int ry, float* ms) -> int {
         cfg.tuned_rows = ry;
         CSIM_HIP(hipEventRecord(e0, s->s_comp));
-        CSIM_HIP(launch_sweepO(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, cfg, kind, s->bc_value, T, 0, s->s_comp));
+        CSIM_HIP(launch_sweepO(s->cur, s->nxt, s->nx, s->ny, s->pitch, p, cfg, kind, s->bc_value, T, part, s->s_comp));
         CSIM_HIP(hipEventRecord(e1, s->s_comp));
         CSIM_HIP(hipEventSynchronize(e1));
         CSIM_HIP(hipEventElapsedTime(ms, e0, e1));
@@ -1291,7 +1359,8 @@ static int tune_rows(csim_stepper* s, const Phys& p, int T) {
     size_t arg = order[0];
     for (size_t q = 1; q < finalists; ++q)
         if (best[order[q]] < best[arg]) arg = order[q];
-    s->cfg.tuned_rows = cand[arg];
+    s->tuned_T[T] = cand[arg];
+    if (preferred_depth) s->cfg.tuned_rows = cand[arg];
     return CSIM_OK;
 }
 
@@ -1324,7 +1393,6 @@ static const double* step_cost_table(long tile_cells) {
     return tile_cells >= SMALL_TILE_CELLS ? STEP_COST_MIDSMALL : STEP_COST_SMALL;
 }
 static const double PASS_COST = 0.1;   // launch and inter-kernel gap, in time steps of the preferred depth
-static const long SHORT_RUN_PASSES = 16;  // overlap 5: runs of fewer passes go bulk-first (see pass_fused_bulk_first)
 // The plan is `lead` passes of depth `lead_depth` followed by the passes listed in `tail` (a run of 10^9
 // steps must not materialise 10^8 entries).
 struct PassPlan {
@@ -1402,11 +1470,24 @@ int csim_pass_schedule(int nsteps, int smallest_tile, long tile_cells, int fuse,
 // the one-off trial of csim_stepper_run's first long call, on request (e.g. before a timed loop)
 int csim_stepper_tune(csim_stepper* s, double D, double dt, double vx, double vy) {
     CSIM_REQUIRE(s, "null stepper");
+    CSIM_SETTLE(s);
     const int depth = fused_depth(s);
-    if (depth < 2 || s->tuned || s->cfg.rows_per_chunk != 0) return CSIM_OK;
+    if (depth < 2 || s->cfg.rows_per_chunk != 0) return CSIM_OK;
     Phys p = make_phys(s->dx, s->dy, D, dt, vx, vy, s->contract != 0);
     if (!s->fused_2c) p.fast_thr = 0.0;
-    return tune_rows(s, p, depth);
+    if (!s->tuned) {
+        int rc = tune_rows(s, p, depth);
+        if (rc) return rc;
+    }
+    // the other depths an automatic pass plan mixes in (20 steps = 7 + 7 + 6, remainders of 4 and 5): each has its own
+    // balance of overhead rows per chunk against rounds of wavefronts, so each gets its own trial
+    if (s->fuse < 0)
+        for (int T = std::min(MAX_FUSE, s->fuse_cap); T >= 4; --T)
+            if (T != depth && s->tuned_T[T] == 0) {
+                int rc = tune_rows(s, p, T, false);
+                if (rc) return rc;
+            }
+    return CSIM_OK;
 }
 
 // Load without effect: whole-tile launches cur -> nxt of the multi-step sweep without a swap (what tune_rows
@@ -1415,6 +1496,7 @@ int csim_stepper_tune(csim_stepper* s, double D, double dt, double vx, double vy
 int csim_stepper_keep_warm(csim_stepper* s, double D, double dt, double vx, double vy, double seconds) {
     CSIM_REQUIRE(s, "null stepper");
     CSIM_REQUIRE(seconds >= 0.0 && seconds <= 10.0, "seconds must be in [0, 10]");
+    CSIM_SETTLE(s);
     const auto t0 = std::chrono::steady_clock::now();
     auto elapsed = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
     const int depth = fused_depth(s);
@@ -1469,15 +1551,18 @@ int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy,
     // Every pass is fused, the last one as `final_pass` (see pass_fused); a run of two or more
     // steps never contains a single-step pass.
     if (can_fuse && s->autotune && !s->tuned && s->cfg.rows_per_chunk == 0 && nsteps >= 4 * depth) {
+        CSIM_SETTLE(s);
         int rc = tune_rows(s, p, depth);
         if (rc) return rc;
     }
     PassPlan plan;
     plan_passes(nsteps, cap, !auto_depth, s->tile_cells, plan);
-    // exchange schedule of this run: bulk-first where asked for, or (overlap 5) on runs too short to
-    // amortise the one exchange per call that the frame-first schedules cannot hide
-    s->bulk_first_run = s->multi && !s->external &&
-                        (s->overlap == 4 || (s->overlap == 5 && plan.size() < SHORT_RUN_PASSES));
+    // exchange schedule of this run: bulk-first (4, and the default 5).  Until round 3 the default went bulk-first only on
+    // runs of fewer than 16 passes and merged (3) otherwise; with the relay (pass_fused_bulk_first) bulk-first is the
+    // faster one at every run length on every per-GPU tile of the 16384^2 run (self-linked torus, 1200-step runs:
+    // 4096 x 8192 1.26-1.27 M against 1.11-1.19 M merged, 8192 x 16384 1.49-1.50 M against 1.45 M, 8192^2 equal), and
+    // it needs nothing but stream order and events: no in-kernel flag, no hipStreamWaitValue64, no write-through stores.
+    s->bulk_first_run = s->multi && !s->external && (s->overlap == 4 || s->overlap == 5);
     for (long k = 0; k < plan.size(); ++k) {
         const int t = plan.at(k);
         int rc;
@@ -1538,6 +1623,7 @@ int csim_stepper_sync(csim_stepper* s) {
 // add up modulo 2^64 to the checksum of the same global field on one rank.
 int csim_stepper_checksum(csim_stepper* s, unsigned long long* out) {
     CSIM_REQUIRE(s && out, "null argument");
+    CSIM_SETTLE(s);
     const long nxg = s->dec.nx_global > 0 ? s->dec.nx_global : s->nx;
     CSIM_HIP(launch_checksum(s->cur, s->nx, s->ny, s->pitch, s->dec.x_offset, s->dec.y_offset, nxg, s->scratch, s->s_comp));
     const int nb = reduce_blocks(s->ny);
@@ -1552,12 +1638,14 @@ int csim_stepper_checksum(csim_stepper* s, unsigned long long* out) {
 
 int csim_stepper_minmax(csim_stepper* s, double out[2]) {
     CSIM_REQUIRE(s && out, "null argument");
+    CSIM_SETTLE(s);
     CSIM_HIP(launch_minmax(s->cur, s->nx, s->ny, s->pitch, s->scratch, s->s_comp));
     return finish_partials(s->scratch, reduce_blocks(s->ny + 2), 0, out, s->s_comp);
 }
 
 int csim_stepper_sum(csim_stepper* s, double* out) {
     CSIM_REQUIRE(s && out, "null argument");
+    CSIM_SETTLE(s);
     double r[2];
     CSIM_HIP(launch_sum(s->cur, s->nx, s->ny, s->pitch, s->scratch, s->s_comp));
     int rc = finish_partials(s->scratch, reduce_blocks(s->ny), 1, r, s->s_comp);
@@ -1582,8 +1670,7 @@ int csim_stepper_set_option(csim_stepper* s, const char* key, long value) {
     } else if (k == "tail_split") {
         CSIM_REQUIRE(value >= 0 && value <= 2, "tail_split must be 0, 1 or 2");
         s->cfg.tail_split = static_cast<int>(value);
-        s->tuned = false;  // the best chunk height depends on it
-        s->cfg.tuned_rows = 0;
+        s->forget_tuning();  // the best chunk height depends on it
     } else if (k == "overlap") {
         CSIM_REQUIRE(value >= 0 && value <= 5 && value != 2, "overlap must be 0, 1, 3, 4 or 5");
         // the schedules hand state to each other only through "nothing in flight": every csim_stepper_run ends that way
@@ -1600,6 +1687,9 @@ int csim_stepper_set_option(csim_stepper* s, const char* key, long value) {
         s->cfg.frame_rows = static_cast<int>(value);
     } else if (k == "frame_prio") {
         s->frame_prio = value != 0;
+    } else if (k == "relay") {
+        CSIM_SETTLE(s);
+        s->relay = value != 0;
     } else if (k == "direct_faces") {
         s->direct_faces = value != 0;
     } else if (k == "fused_2c") {
@@ -1609,10 +1699,7 @@ int csim_stepper_set_option(csim_stepper* s, const char* key, long value) {
         s->halo_fresh = false;
     } else if (k == "contract") {
         CSIM_REQUIRE(value == 0 || value == 1, "contract must be 0 (reference operation order, default) or 1");
-        if (s->contract != static_cast<int>(value)) {  // another kernel: its best chunk height is found anew
-            s->tuned = false;
-            s->cfg.tuned_rows = 0;
-        }
+        if (s->contract != static_cast<int>(value)) s->forget_tuning();  // another kernel: its best chunk height is found anew
         s->contract = static_cast<int>(value);
     } else if (k == "fuse") {
         CSIM_REQUIRE(value >= -1 && value <= MAX_FUSE, "fuse must be -1 (auto) or 0..7");
@@ -1622,8 +1709,7 @@ int csim_stepper_set_option(csim_stepper* s, const char* key, long value) {
         s->cfg.lds_bytes = static_cast<int>(value);
     } else if (k == "autotune") {
         s->autotune = value != 0;
-        s->tuned = false;
-        s->cfg.tuned_rows = 0;
+        s->forget_tuning();
     } else if (k == "tuned_rows" || k == "last_rows") {  // read back through csim_stepper_get_option
         return fail(CSIM_ERR_ARG, k + " is read-only");
     } else if (k == "sync_timeout_ms") {
@@ -1661,12 +1747,15 @@ int csim_stepper_get_option(const csim_stepper* s, const char* key, long* value)
     if (k == "variant") *value = s->cfg.variant;
     else if (k == "rows_per_chunk") *value = s->cfg.rows_per_chunk;
     else if (k == "tuned_rows") *value = s->cfg.tuned_rows;
+    else if (k.size() == 12 && k.compare(0, 11, "tuned_rows_") == 0 && k[11] >= '2' && k[11] <= '0' + MAX_FUSE)
+        *value = s->tuned_T[k[11] - '0'];  // "tuned_rows_2" .. "tuned_rows_7": the trial's result for passes of that depth (0 = none)
     else if (k == "last_rows") *value = s->last_rows;
     else if (k == "prefetch") *value = s->cfg.prefetch;
     else if (k == "xcd_swizzle") *value = s->cfg.xcd_swizzle;
     else if (k == "tail_split") *value = s->cfg.tail_split;
     else if (k == "overlap") *value = s->overlap;
     else if (k == "direct_faces") *value = s->direct_faces;
+    else if (k == "relay") *value = s->relay;
     else if (k == "fused_2c") *value = s->fused_2c;
     else if (k == "fused_2c_active") *value = s->fused_2c_active;
     else if (k == "frame_rows") *value = s->cfg.frame_rows;

@@ -178,14 +178,18 @@ int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy,
 int csim_pass_schedule(int nsteps, int smallest_tile, long tile_cells, int fuse, int* depths, int max_depths,
                        long* npasses);
 /* optional, before a timed loop: the one-off rows-per-chunk trial that the first long
- * csim_stepper_run would otherwise do (option "autotune"); does not advance the field */
+ * csim_stepper_run would otherwise do (option "autotune"), and — with automatic pass depths — a trial for every
+ * other depth a pass plan may mix in (4..7; read back as "tuned_rows_4" .. "tuned_rows_7"); does not advance the field */
 int csim_stepper_tune(csim_stepper* s, double D, double dt, double vx, double vy);
 /* measurement helper: keep this GPU under the stepper's own load for about `seconds` WITHOUT advancing the field
  * and without any communication (whole-tile launches of the multi-step sweep into the scratch buffer, like the
  * trial launches of _tune), returning with the GPU idle not later than `seconds` after the call.  For the wait
  * between a cross-rank barrier and a timed region (reference: the MPI_Wtime bracket of src/main.cpp:94,111 has no
  * such wait): a GPU that idles for milliseconds leaves its sustained power state and runs the first launches of
- * the timed region 5-15 % slower. */
+ * the timed region 5-15 % slower.  On a multi-rank stepper these launches (like the trial launches of _tune) read the
+ * deep-halo layers as they are — zero after creation, otherwise the faces of an earlier pass — so their duration is
+ * that of a real pass only while those values are finite (a NaN there makes "fused_2c" tiles run twice); the field
+ * itself is never affected. */
 int csim_stepper_keep_warm(csim_stepper* s, double D, double dt, double vx, double vy, double seconds);
 /* waits for everything enqueued.  With an RCCL communicator the wait polls ncclCommGetAsyncError, so a failed
  * exchange returns CSIM_ERR_RCCL instead of hanging (the reference's MPI_Waitall, src/halo.cpp:46, aborts through
@@ -223,7 +227,10 @@ int csim_stepper_sum(csim_stepper* s, double* out);
  *                    stream waits on (hipStreamWaitValue64), so the exchange starts under the running kernel
  *                    without an event or a second launch (without signal memory: as 1); 4 bulk launch first with
  *                    THIS pass's exchange under it, then the frame launch — no pass of a run, not even the first,
- *                    waits for an unhidden exchange; 5 (default) = 4 on runs of fewer than 16 passes, 3 otherwise
+ *                    waits for an unhidden exchange, and only stream order and events are involved; 5 (default) = 4
+ *   "relay"          0/1 (default 1), schedule 4: the two streams swap roles every pass, so that the frame launch follows
+ *                    the exchange chain, and the next pass's bulk launch the frame launch, on the same stream (no event
+ *                    hand-off on the way of the data)
  *   "direct_faces"   0/1 (default 1), schedule 3: the frame wavefronts copy the cells that form the NEXT pass's faces
  *                    straight into the RCCL send buffers before they publish the flag (0: a pack kernel on the
  *                    comm stream does it after the flag)

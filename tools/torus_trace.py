@@ -27,8 +27,13 @@ t0 = time.perf_counter()
 while time.perf_counter() - t0 < 0.3:
     st.run(0.05, 0.1, 0.5, 0.25, 60)
     st.sync()
+run = int(os.environ.get("RUN", "0"))   # steps per csim_stepper_run call (0: one call of 120 steps)
 t0 = time.perf_counter()
-st.run(0.05, 0.1, 0.5, 0.25, 120)
+if run > 0:
+    for _ in range(120 // run):
+        st.run(0.05, 0.1, 0.5, 0.25, run)
+else:
+    st.run(0.05, 0.1, 0.5, 0.25, 120)
 st.sync()
-print(mode, nx, ny, "ms/step", (time.perf_counter() - t0) / 120 * 1e3)
+print(mode, nx, ny, "steps per call", run or 120, "ms/step", (time.perf_counter() - t0) / 120 * 1e3)
 st.close()
