@@ -37,6 +37,10 @@ def edges(u, nbr):
 
 
 def main():
+    # a rank that is stuck (rendezvous, a peer that died, a stream that never drains) says WHERE and leaves, so that
+    # the launching test fails with a stack instead of sitting out its timeout
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("CSIM_WORKER_WATCHDOG_S", "150")), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--engine", default="oracle")
     ap.add_argument("--case", required=True, help="path of a tests/golden/run_*.npz fixture")
