@@ -514,7 +514,8 @@ def main():
     case_steppers = {}
     torus_ref = {}
     pre = dict(golden_cases=[c[0] for c in cases], schedules={}, ok=True,
-               golden_reference=("the reference's own mpirun -np %d runs (tests/golden, per-rank local arrays incl. ghost "
+               golden_reference=None if not cases else
+                                ("the reference's own mpirun -np %d runs (tests/golden, per-rank local arrays incl. ghost "
                                  "lines)" % world) if not self_torus else
                                 "schedule 0 on the same inputs (the self-linked torus is not a reference topology)",
                checksum_steps=list(CHECK_STEPS))

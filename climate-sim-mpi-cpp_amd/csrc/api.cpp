@@ -10,6 +10,12 @@ int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
 }
+static bool pow2(double x) {
+    if (!(x > 0.0) || !std::isnormal(x)) return false;
+    int e = 0;
+    return std::frexp(x, &e) == 0.5 && std::isnormal(1.0 / x);
+}
+
 Phys make_phys(double dx, double dy, double D, double dt, double vx, double vy, bool contract) {
     Phys p;
     p.kdiff = dt * D;

@@ -5,7 +5,6 @@
 
 using namespace csim;
 
-static int post_exchange(csim_stepper* s, hipStream_t st) { return post_plan(s, 1, st); }
 static int post_exchange2(csim_stepper* s, int H, hipStream_t st) { return post_plan(s, H, st); }
 // T = 2..7 reference steps in one HBM pass.  Several ranks: faces of depth T (8 directions) are
 // staged in recv2[]; when the next pass is fused too (with `next_T` steps), the frame tiles are
@@ -54,14 +53,16 @@ static int pass_fused_bulk_first(csim_stepper* s, const Phys& p, int T, bool fin
     if (!s->relay) CSIM_SETTLE(s);
     hipStream_t X = s->tail ? s->tail : s->s_comp;
     hipStream_t Y = X == s->s_comp ? s->s_comm : s->s_comp;
+    const bool light = s->relay && s->relay_events;
+    hipEvent_t ev_state = light ? s->ev_relay_ready : s->ev_ready, ev_bulk = light ? s->ev_relay_bulk : s->ev_edge2;
     // everything enqueued so far on X produced `cur` (and the partner buffer's ring)
-    CSIM_HIP(hipEventRecord(s->ev_ready, X));
-    CSIM_HIP(hipStreamWaitEvent(Y, s->ev_ready, 0));
+    CSIM_HIP(hipEventRecord(ev_state, X));
+    CSIM_HIP(hipStreamWaitEvent(Y, ev_state, 0));
     int rc = prof_begin(s, T, X);
     if (rc) return rc;
     // the bulk goes out first: the GPU starts on it while the host is still enqueuing the exchange
     CSIM_HIP(launch_fused(s, p, kind, T, 2, X));  // nothing to launch on tiles that are all frame
-    if (s->relay) CSIM_HIP(hipEventRecord(s->ev_edge2, X));  // the bulk's end, for whatever follows the frame on Y
+    if (s->relay) CSIM_HIP(hipEventRecord(ev_bulk, X));  // the bulk's end, for whatever follows the frame on Y
     long comm_slot = -1;
     rc = prof_start(s, csim_stepper::PROF_COMM, Y, &comm_slot);
     if (rc) return rc;
@@ -82,7 +83,7 @@ static int pass_fused_bulk_first(csim_stepper* s, const Phys& p, int T, bool fin
     rc = prof_end(s, F);
     if (rc) return rc;
     if (s->relay) {
-        CSIM_HIP(hipStreamWaitEvent(Y, s->ev_edge2, 0));  // the field is complete on Y once the bulk is done too
+        CSIM_HIP(hipStreamWaitEvent(Y, ev_bulk, 0));  // the field is complete on Y once the bulk is done too
         s->tail = Y;
     }
     std::swap(s->cur, s->nxt);

@@ -103,6 +103,8 @@ int csim_stepper_create(const csim_decomp* dec, double dx, double dy, const int 
         ok(hipMemset(s->buf[0], 0, s->bytes())) && ok(hipMemset(s->buf[1], 0, s->bytes())) &&
         ok(hipMalloc(reinterpret_cast<void**>(&s->scratch), sizeof(double) * 2 * REDUCE_BLOCKS)) &&
         ok(hipEventCreateWithFlags(&s->ev_tail, hipEventDisableTiming)) &&
+        ok(hipEventCreateWithFlags(&s->ev_relay_ready, hipEventDisableTiming | hipEventDisableSystemFence)) &&
+        ok(hipEventCreateWithFlags(&s->ev_relay_bulk, hipEventDisableTiming | hipEventDisableSystemFence)) &&
         ok(hipEventCreateWithFlags(&s->ev_ready, hipEventDisableTiming)) &&
         ok(hipEventCreateWithFlags(&s->ev_edge, hipEventDisableTiming)) &&
         ok(hipEventCreateWithFlags(&s->ev_recv, hipEventDisableTiming));
@@ -217,6 +219,8 @@ int csim_stepper_destroy(csim_stepper* s) {
     if (s->s_comm) (void)hipStreamDestroy(s->s_comm);
     if (s->ev_ready) (void)hipEventDestroy(s->ev_ready);
     if (s->ev_tail) (void)hipEventDestroy(s->ev_tail);
+    if (s->ev_relay_ready) (void)hipEventDestroy(s->ev_relay_ready);
+    if (s->ev_relay_bulk) (void)hipEventDestroy(s->ev_relay_bulk);
     if (s->buf[0]) (void)hipFree(s->buf[0]);
     if (s->buf[1]) (void)hipFree(s->buf[1]);
     if (s->scratch) (void)hipFree(s->scratch);
@@ -523,6 +527,9 @@ int csim_stepper_set_option(csim_stepper* s, const char* key, long value) {
     } else if (k == "relay") {
         CSIM_SETTLE(s);
         s->relay = value != 0;
+    } else if (k == "relay_events") {
+        CSIM_REQUIRE(value == 0 || value == 1, "relay_events must be 0 or 1");
+        s->relay_events = static_cast<int>(value);
     } else if (k == "direct_faces") {
         s->direct_faces = value != 0;
     } else if (k == "fused_2c") {
@@ -589,6 +596,7 @@ int csim_stepper_get_option(const csim_stepper* s, const char* key, long* value)
     else if (k == "overlap") *value = s->overlap;
     else if (k == "direct_faces") *value = s->direct_faces;
     else if (k == "relay") *value = s->relay;
+    else if (k == "relay_events") *value = s->relay_events;
     else if (k == "fused_2c") *value = s->fused_2c;
     else if (k == "fused_2c_active") *value = s->fused_2c_active;
     else if (k == "frame_rows") *value = s->cfg.frame_rows;

@@ -33,12 +33,6 @@
         if (!(cond)) return ::csim::fail(CSIM_ERR_ARG, msg); \
     } while (0)
 
-static bool pow2(double x) {
-    if (!(x > 0.0) || !std::isnormal(x)) return false;
-    int e = 0;
-    return std::frexp(x, &e) == 0.5 && std::isnormal(1.0 / x);
-}
-
 
 struct csim_stepper {
     csim_decomp dec{};
@@ -61,6 +55,10 @@ struct csim_stepper {
     // On multi-rank steppers both streams have the same (high) priority: they carry the same kinds of work in turn.
     hipStream_t tail = nullptr;
     hipEvent_t ev_tail = nullptr;
+    // relay hand-offs between the two streams of THIS device (kernel boundaries carry the agent-scope release / acquire):
+    // events without the system-scope fence a default event performs when it is recorded (option "relay_events")
+    hipEvent_t ev_relay_ready = nullptr, ev_relay_bulk = nullptr;
+    int relay_events = 0;  // 1: the relay records ev_relay_* instead of ev_ready / ev_edge2
     int relay = 1;
     hipEvent_t ev_edge = nullptr, ev_recv = nullptr, ev_ready = nullptr;
     ncclComm_t comm = nullptr;

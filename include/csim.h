@@ -230,7 +230,9 @@ int csim_stepper_sum(csim_stepper* s, double* out);
  *                    waits for an unhidden exchange, and only stream order and events are involved; 5 (default) = 4
  *   "relay"          0/1 (default 1), schedule 4: the two streams swap roles every pass, so that the frame launch follows
  *                    the exchange chain, and the next pass's bulk launch the frame launch, on the same stream (no event
- *                    hand-off on the way of the data)
+ *                    hand-off on the way of the data); "relay_events" 0/1 (default 0, experiment): the relay's cross-stream
+ *                    events without the system-scope fence of a default event (+1 % on 20-step calls of the 8-GPU tile;
+ *                    left off: what it skips is also what makes the field visible to other agents)
  *   "direct_faces"   0/1 (default 1), schedule 3: the frame wavefronts copy the cells that form the NEXT pass's faces
  *                    straight into the RCCL send buffers before they publish the flag (0: a pack kernel on the
  *                    comm stream does it after the flag)

@@ -10,7 +10,7 @@ set -x
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
-TAG=${TAG:-r02}
+TAG=${TAG:-r03}
 cd /tmp
 if [ "${SKIP_BENCH:-0}" != "1" ]; then
   timeout -k 10 900 python3 $R/bench.py > $R/gpurun_out/bench_full.log 2> $R/gpurun_out/bench_full.err || exit 1
