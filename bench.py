@@ -509,7 +509,9 @@ def main():
     # ------------------------------------------------------------------------------------------------------
     # parity preflight
     # ------------------------------------------------------------------------------------------------------
-    cases = golden_cases(world) if (rccl and not self_torus) else (golden_cases(1) if self_torus else [])
+    # (over the host-staged fall-back transport the same cases run in external-halo mode: the comparison logic is the
+    # same, and a two-rank run on ONE GPU — tests/test_gpu_bench.py — exercises it)
+    cases = golden_cases(world) if (multi and not self_torus) else (golden_cases(1) if self_torus else [])
     cases = [c for c in cases if min(c[2]["nx"], c[2]["ny"]) >= 2]
     case_steppers = {}
     torus_ref = {}
@@ -540,7 +542,10 @@ def main():
                     for k in range(4):
                         d.nbr[k] = 0
                 ps = csim.Stepper(d, m["dx"], m["dy"], csim.bc_codes(m["bc"]))
-                ps.comm_share(st)
+                if rccl:
+                    ps.comm_share(st)
+                else:
+                    ps.set_option("external_halo", 1)
                 case_steppers[key] = (ps, d)
             ps, d = case_steppers[key]
             set_schedule(ov, ps)
@@ -548,9 +553,13 @@ def main():
             u[1:-1, 1:-1] = z["u0"][d.y_offset:d.y_offset + d.ny_local, d.x_offset:d.x_offset + d.nx_local]
             ps.upload(u)
             cdt = float(z["dt_effective"])
-            ps.run(m["D"], cdt, m["vx"], m["vy"], 1)                       # uneven calls: a single step, then the rest
-            if m["steps"] > 1:
-                ps.run(m["D"], cdt, m["vx"], m["vy"], m["steps"] - 1)
+            if rccl:
+                ps.run(m["D"], cdt, m["vx"], m["vy"], 1)                   # uneven calls: a single step, then the rest
+                if m["steps"] > 1:
+                    ps.run(m["D"], cdt, m["vx"], m["vy"], m["steps"] - 1)
+            else:
+                from climate_sim_mpi_cpp_amd.host_transport import advance as advance_external
+                advance_external(ps, list(d.nbr), m["D"], cdt, m["vx"], m["vy"], m["steps"])
             ps.sync()
             got = ps.download()
             if self_torus:

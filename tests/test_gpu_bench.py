@@ -141,3 +141,9 @@ def test_bench_two_ranks_host_staged_fallback():
     assert r["n_gpus"] == 2 and r["scaling"] == "strong"
     assert r["config"]["halo_transport"].startswith("gloo")
     assert r["config"]["relative_mass_drift"] < 1e-9
+    # the parity preflight of a REAL two-rank run: every rank compared its tile of the reference's own `mpirun -np 2`
+    # golden cases (ghost lines included) and the two ranks' checksums of the bench field add up to the oracle's value
+    pre = r["config"]["parity_preflight"]
+    assert pre["ok"] and len(pre["golden_cases"]) >= 7 and "mpirun -np 2" in pre["golden_reference"]
+    (rec,) = pre["schedules"].values()
+    assert rec["golden_ok"] is True and rec["checksum_ok"] is True and rec["checksum"] == pre["checksum_expected"]
