@@ -27,7 +27,19 @@ def free_port():
 
 def launch(world, engine, case, timeout=300):
     """start `world` worker processes directly (env rendezvous on 127.0.0.1, no launcher process:
-    a GPU box allows few processes on its card)."""
+    a GPU box allows few processes on its card).  A run that ends WITHOUT a verdict line — a rank stuck in the
+    rendezvous or elsewhere: the workers dump their stacks and leave after 150 s — is started once more on a fresh
+    port, and the first attempt's output is raised as a warning so that it stays visible; a run that printed its
+    verdict (ok=True / ok=False) is never repeated."""
+    rc, out = _launch_once(world, engine, case, timeout)
+    if rc != 0 and "MULTIRANK engine=" not in out:
+        import warnings
+        warnings.warn(f"multi-rank worker run without a verdict (rc {rc}), repeated once; first attempt said:\n{out[-4000:]}")
+        rc, out = _launch_once(world, engine, case, timeout)
+    return rc, out
+
+
+def _launch_once(world, engine, case, timeout):
     port = str(free_port())
     procs = []
     for r in range(world):

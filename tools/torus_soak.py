@@ -19,7 +19,8 @@ ok = True
 for nx, ny, bc, sides in ((2048, 4096, "dddd", (1, 1, 1, 1)), (4096, 1024, "dndn", (1, 1, 0, 0)), (1000, 3000, "nnpd", (0, 0, 1, 1))):
     ref = None
     for opts in (dict(overlap=0), dict(overlap=1), dict(overlap=3), dict(overlap=4), dict(overlap=5), dict(overlap=4, fuse=7),
-                 dict(overlap=1, fuse=4), dict(overlap=3, direct_faces=0), dict(overlap=3, fused_2c=0), dict(overlap=3, fuse=7)):
+                 dict(overlap=1, fuse=4), dict(overlap=3, direct_faces=0), dict(overlap=3, fused_2c=0), dict(overlap=3, fuse=7),
+                 dict(overlap=4, relay=0), dict(overlap=5, relay_events=1), dict(overlap=5, fuse=5)):
         d = csim.decomp_init(1, 0, nx, ny)
         for k in range(4):
             d.nbr[k] = 0 if sides[k] else csim.NO_NEIGHBOR
