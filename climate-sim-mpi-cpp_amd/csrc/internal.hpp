@@ -92,7 +92,7 @@ struct FrameSync {
     unsigned long long pass = 0;
     unsigned nframe = 0;  // filled in by the launcher
     int fence = 0;        // 0 write-through result stores + drain (default), 1 plain stores + agent-scope fence per
-                          // wavefront (slow), 2 plain stores, drain only (timing experiments: NOT safe)
+                          // wavefront (slow: +40 us per pass)
     int prio = 1;         // frame wavefronts raise their issue priority
     // direct faces (face_depth > 0): the frame wavefronts also copy the cells that form the faces of the NEXT pass
     // (depth face_depth, k_halo2_pack's layout) straight into the send buffers; nullptr = no peer in that direction

@@ -771,12 +771,7 @@ __global__ __launch_bounds__(256) void k_sweepO_dpp(const double* __restrict__ i
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
         }
-        if (fs.fence == 0)
-            ;
-        else if (fs.fence == 1)
-            __threadfence();
-        else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // experiment only: plain stores drained, NOT written back
+        if (fs.fence == 1) __threadfence();  // plain result stores + agent-scope fence per wavefront (measured alternative)
         // Ordering (ISA level; no C++ happens-before is claimed): every store of this wavefront that a consumer may
         // read — tile results and face copies — is an agent-scope write-through store (global_store ... sc1), and the
         // s_waitcnt vmcnt(0) above returns only once each of them has been acknowledged by memory.  The counter

@@ -517,7 +517,7 @@ int csim_stepper_set_option(csim_stepper* s, const char* key, long value) {
             return fail(CSIM_ERR_STATE, "overlap 3 needs hipStreamWaitValue64 / signal memory, which this device or runtime refused");
         s->overlap = static_cast<int>(value);
     } else if (k == "frame_fence") {
-        CSIM_REQUIRE(value >= 0 && value <= 2, "frame_fence must be 0..2");
+        CSIM_REQUIRE(value == 0 || value == 1, "frame_fence must be 0 or 1");
         s->frame_fence = static_cast<int>(value);
     } else if (k == "frame_rows") {
         CSIM_REQUIRE(value >= 0 && value <= 4096, "frame_rows must be 0..4096");
