@@ -49,11 +49,23 @@ static int pass_fused_bulk_first(csim_stepper* s, const Phys& p, int T, bool fin
     // on the way of data (Y's chain waits for X's state) sits under the bulk.  Without the relay the frame launch waits
     // for the chain through an event (~12 us from the record to the launch it releases) and the next pass's bulk
     // follows the frame through another record / wait pair (~8 us): 20 of the ~205 us of a 7-step pass on the 8-GPU
-    // tile (profiles/r03_timeline_torus20.txt).
-    if (!s->relay) CSIM_SETTLE(s);
-    hipStream_t X = s->tail ? s->tail : s->s_comp;
-    hipStream_t Y = X == s->s_comp ? s->s_comm : s->s_comp;
-    const bool light = s->relay && s->relay_events;
+    // tile (profiles/r03_timeline_torus20_before.txt, _after.txt).
+    hipStream_t X, Y;
+    if (!s->relay || !s->s_relay[0]) {  // round 2's form: bulk and frame on the compute stream, the chain on the comm stream
+        CSIM_SETTLE(s);
+        X = s->s_comp;
+        Y = s->s_comm;
+    } else {
+        if (s->tail != s->s_relay[0] && s->tail != s->s_relay[1]) {  // first relay pass since something else ran: hand over
+            CSIM_HIP(hipEventRecord(s->ev_tail, s->tail ? s->tail : s->s_comp));
+            CSIM_HIP(hipStreamWaitEvent(s->s_relay[0], s->ev_tail, 0));
+            s->tail = s->s_relay[0];
+        }
+        X = s->tail;
+        Y = X == s->s_relay[0] ? s->s_relay[1] : s->s_relay[0];
+    }
+    const bool relay = X != s->s_comp;
+    const bool light = relay && s->relay_events;
     hipEvent_t ev_state = light ? s->ev_relay_ready : s->ev_ready, ev_bulk = light ? s->ev_relay_bulk : s->ev_edge2;
     // everything enqueued so far on X produced `cur` (and the partner buffer's ring)
     CSIM_HIP(hipEventRecord(ev_state, X));
@@ -62,7 +74,7 @@ static int pass_fused_bulk_first(csim_stepper* s, const Phys& p, int T, bool fin
     if (rc) return rc;
     // the bulk goes out first: the GPU starts on it while the host is still enqueuing the exchange
     CSIM_HIP(launch_fused(s, p, kind, T, 2, X));  // nothing to launch on tiles that are all frame
-    if (s->relay) CSIM_HIP(hipEventRecord(ev_bulk, X));  // the bulk's end, for whatever follows the frame on Y
+    if (relay) CSIM_HIP(hipEventRecord(ev_bulk, X));  // the bulk's end, for whatever follows the frame on Y
     long comm_slot = -1;
     rc = prof_start(s, csim_stepper::PROF_COMM, Y, &comm_slot);
     if (rc) return rc;
@@ -74,7 +86,7 @@ static int pass_fused_bulk_first(csim_stepper* s, const Phys& p, int T, bool fin
     rc = prof_stop(s, comm_slot, Y);
     if (rc) return rc;
     hipStream_t F = Y;  // the frame launch follows the chain on its own stream
-    if (!s->relay) {
+    if (!relay) {
         CSIM_HIP(hipEventRecord(s->ev_recv2, Y));
         CSIM_HIP(hipStreamWaitEvent(X, s->ev_recv2, 0));
         F = X;
@@ -82,7 +94,7 @@ static int pass_fused_bulk_first(csim_stepper* s, const Phys& p, int T, bool fin
     CSIM_HIP(launch_fused(s, p, kind, T, 1, F, final_pass));
     rc = prof_end(s, F);
     if (rc) return rc;
-    if (s->relay) {
+    if (relay) {
         CSIM_HIP(hipStreamWaitEvent(Y, ev_bulk, 0));  // the field is complete on Y once the bulk is done too
         s->tail = Y;
     }

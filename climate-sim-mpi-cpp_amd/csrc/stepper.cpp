@@ -148,8 +148,13 @@ int csim_stepper_create(const csim_decomp* dec, double dx, double dy, const int 
         int lo = 0, hi = 0;  // numerically lower = higher priority
         ok(hipDeviceGetStreamPriorityRange(&lo, &hi)) &&
             ok(hipStreamCreateWithPriority(&s->s_comm, hipStreamNonBlocking, hi)) &&
-            (s->multi ? ok(hipStreamCreateWithPriority(&s->s_comp, hipStreamNonBlocking, hi))
-                      : ok(hipStreamCreateWithFlags(&s->s_comp, hipStreamNonBlocking)));
+            ok(hipStreamCreateWithFlags(&s->s_comp, hipStreamNonBlocking));
+        // the relay pair of the bulk-first passes: two streams of EQUAL (high) priority — they carry the same kinds of
+        // work in turn —, apart from the compute stream, which keeps its normal priority below the comm stream for
+        // the frame-first schedules (their exchange kernels must be dispatched ahead of the sweep that hides them)
+        if (s->multi)
+            ok(hipStreamCreateWithPriority(&s->s_relay[0], hipStreamNonBlocking, hi)) &&
+                ok(hipStreamCreateWithPriority(&s->s_relay[1], hipStreamNonBlocking, hi));
         s->tail = s->s_comp;
     }
     if (e == hipSuccess) {
@@ -192,6 +197,8 @@ int csim_stepper_destroy(csim_stepper* s) {
     if (!s) return CSIM_OK;
     if (s->s_comp) (void)hipStreamSynchronize(s->s_comp);
     if (s->s_comm) (void)hipStreamSynchronize(s->s_comm);
+    for (hipStream_t r : s->s_relay)
+        if (r) (void)hipStreamSynchronize(r);
     if (s->s_io) (void)hipStreamSynchronize(s->s_io);
     if (s->snap_d) (void)hipFree(s->snap_d);
     if (s->snap_h) (void)hipHostFree(s->snap_h);
@@ -216,6 +223,8 @@ int csim_stepper_destroy(csim_stepper* s) {
     if (s->ev_edge) (void)hipEventDestroy(s->ev_edge);
     if (s->ev_recv) (void)hipEventDestroy(s->ev_recv);
     if (s->s_comp) (void)hipStreamDestroy(s->s_comp);
+    for (hipStream_t r : s->s_relay)
+        if (r) (void)hipStreamDestroy(r);
     if (s->s_comm) (void)hipStreamDestroy(s->s_comm);
     if (s->ev_ready) (void)hipEventDestroy(s->ev_ready);
     if (s->ev_tail) (void)hipEventDestroy(s->ev_tail);
@@ -453,6 +462,11 @@ int csim_stepper_sync(csim_stepper* s) {
     const auto t0 = std::chrono::steady_clock::now();
     int rc = wait_stream(s, s->s_comp, t0);
     if (rc) return rc;
+    for (hipStream_t r : s->s_relay)
+        if (r) {
+            rc = wait_stream(s, r, t0);
+            if (rc) return rc;
+        }
     return wait_stream(s, s->s_comm, t0);
 }
 

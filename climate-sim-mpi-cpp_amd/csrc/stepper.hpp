@@ -49,10 +49,10 @@ struct csim_stepper {
     double* recv[4]{nullptr, nullptr, nullptr, nullptr};
     double* fin[4]{nullptr, nullptr, nullptr, nullptr};  // FinLines of the last fused pass of a run (all sides)
     hipStream_t s_comp = nullptr, s_comm = nullptr;
-    // Relay (bulk-first passes): the two streams swap roles every pass — the stream that carried a pass's exchange and
-    // frame launch also takes the NEXT pass's bulk launch — so `tail` names the stream on which the current field
-    // state is ordered.  Every entry point that is not a relay pass settles it back onto s_comp first (settle()).
-    // On multi-rank steppers both streams have the same (high) priority: they carry the same kinds of work in turn.
+    // Relay (bulk-first passes): two streams of equal priority swap roles every pass — the one that carried a pass's
+    // exchange and frame launch also takes the NEXT pass's bulk launch — so `tail` names the stream on which the current
+    // field state is ordered.  Every entry point that is not a relay pass settles it back onto s_comp first (settle()).
+    hipStream_t s_relay[2]{nullptr, nullptr};
     hipStream_t tail = nullptr;
     hipEvent_t ev_tail = nullptr;
     // relay hand-offs between the two streams of THIS device (kernel boundaries carry the agent-scope release / acquire):
