@@ -118,7 +118,8 @@ def test_config5_32768_on_4x2_all_neumann_tiles_from_a_netcdf_ic_file(csim, ora,
     n, steps, bc = 32768, 9, "nnnn"
     D, vx, vy, dt = 0.05, 0.5, 0.25, 0.1
     free = os.statvfs(tmp_path).f_bavail * os.statvfs(tmp_path).f_frsize
-    assert free > 10 * 2**30, f"needs 8.6 GB of scratch disk for the IC file, {free / 2**30:.1f} GiB free in {tmp_path}"
+    if free < 10 * 2**30:
+        pytest.skip(f"needs 8.6 GB of scratch disk for the IC file, {free / 2**30:.1f} GiB free in {tmp_path}")
     subprocess.run(["make", "-s", "-C", DRV, "csim_hosttool"], check=True)
     u0 = np.random.default_rng(325).random((n, n))
     # the IC file: header by the product's writer (open_netcdf_parallel / close, zero records), the one record
