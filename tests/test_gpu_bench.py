@@ -117,9 +117,12 @@ def test_bench_checksum_fixture_is_what_the_oracle_computes():
     assert csim.checksum_host(w.gather()) == e["checksum"]
 
 
-def test_bench_two_ranks_host_staged_fallback():
-    """two bench ranks sharing this GPU with CSIM_BENCH_HALO=gloo: the fall-back transport bench.py
-    uses when the RCCL communicator cannot be built (RCCL refuses two ranks on one device)"""
+@pytest.mark.parametrize("forced", [True, False])
+def test_bench_two_ranks_host_staged_fallback(forced):
+    """two bench ranks sharing this GPU: the fall-back transport bench.py uses when the RCCL communicator cannot be
+    built.  forced: CSIM_BENCH_HALO=gloo asks for it; not forced: the run first times its host-staged SAFETY-NET region,
+    then really tries RCCL, which refuses two ranks on one device (ncclCommInitRank: invalid usage), and every rank
+    falls back together"""
     import socket
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -127,8 +130,10 @@ def test_bench_two_ranks_host_staged_fallback():
     s.close()
     procs = []
     for r in range(2):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=port, CSIM_BENCH_HALO="gloo", OMP_NUM_THREADS="1")
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=port, OMP_NUM_THREADS="1", CSIM_BENCH_PHASE_TIMEOUT="30")
+        if forced:
+            env.update(CSIM_BENCH_HALO="gloo", LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--nx", "1536",
                                        "--ny", "1024", "--steps", "37", "--warmup", "7", "--ramp-seconds", "0.02"],
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
@@ -140,6 +145,7 @@ def test_bench_two_ranks_host_staged_fallback():
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["scaling"] == "strong"
     assert r["config"]["halo_transport"].startswith("gloo")
+    assert forced or "RCCL unavailable" in r["config"]["halo_transport"]
     assert r["config"]["relative_mass_drift"] < 1e-9
     # the parity preflight of a REAL two-rank run: every rank compared its tile of the reference's own `mpirun -np 2`
     # golden cases (ghost lines included) and the two ranks' checksums of the bench field add up to the oracle's value
