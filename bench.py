@@ -439,6 +439,7 @@ def main():
                                           overlap=None)]
         st.set_option("external_halo", 0)
     if multi:
+        wd.arm(180 + args.phase_timeout, "RCCL communicator")
         # RCCL communicator (unique id over the gloo control plane).  If it cannot be built on this
         # box the run falls back — on every rank — to host-staged faces over gloo, so that a scaling
         # number exists at all; the JSON line says which transport carried the halos.
@@ -556,7 +557,7 @@ def main():
 
     def preflight(ov):
         """golden cases + checksum run under schedule `ov`; returns ok (identical on every rank)"""
-        name = SCHED_NAMES.get(ov, "single GPU")
+        name = SCHED_NAMES.get(ov, "host-staged faces over gloo" if multi else "single GPU")
         rec = dict(golden_ok=None, checksum=None, checksum_ok=None)
         pre["schedules"][name] = rec
         good = True
