@@ -1,9 +1,9 @@
 #!/bin/bash
 # A/B of two builds of the engine on the per-GPU tiles (tools/torus_bench.py) and on the bench grid:
-#   new = climate-sim-mpi-cpp_amd/lib/libcsim.so, old = $OLD_LIB (default climate-sim-mpi-cpp_amd/lib_old/libcsim.so)
+#   new = climate-sim-mpi-cpp_amd/lib/libcsim.so, old = $OLD_LIB (another build of the engine)
 # interleaved twice so that box drift shows.  Output: gpurun_out/lib_ab.jsonl
 R=${GRAFT_REPO_ROOT:-$PWD}
-OLD=${OLD_LIB:-$R/climate-sim-mpi-cpp_amd/lib_old/libcsim.so}
+OLD=${OLD_LIB:?set OLD_LIB to the other build of libcsim.so (e.g. make OUT=../lib_old/libcsim.so OBJDIR=../build_old in a checkout of the other revision)}
 out=$R/gpurun_out/lib_ab.jsonl
 : > $out
 for rnd in 1 2; do
