@@ -1,4 +1,4 @@
-// prototype: overlapped-strip fused sweep with NC columns per lane (interior body only), T = 6
+// prototype: overlapped-strip fused sweep with NC = 2, 3 or 4 columns per lane (interior body only), T = 5, 6, 7
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -49,11 +49,16 @@ __global__ __launch_bounds__(256) void k_proto(const double* __restrict__ in, do
     auto load = [&](int j) {
         Row<NC> r;
         const double* src = in + static_cast<ptrdiff_t>(j) * pitch + xoff;
+        if (NC % 2 == 0) {
 #pragma unroll
-        for (int c = 0; c < NC; c += 2) {
-            const double2 t = *reinterpret_cast<const double2*>(src + c);
-            r.v[c] = t.x;
-            r.v[c + 1] = t.y;
+            for (int c = 0; c + 1 < NC; c += 2) {
+                const double2 t = *reinterpret_cast<const double2*>(src + c);
+                r.v[c] = t.x;
+                r.v[c + 1] = t.y;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) r.v[c] = src[c];
         }
         return r;
     };
@@ -93,12 +98,20 @@ __global__ __launch_bounds__(256) void k_proto(const double* __restrict__ in, do
                     L[l][u % 3] = o;
                 } else if (rho >= jb && rho <= je) {
                     double* dst = out + static_cast<ptrdiff_t>(rho) * pitch + xoff;
+                    if (NC % 2 == 0) {
 #pragma unroll
-                    for (int q = 0; q < NC; q += 2) {
-                        const int lc = NC * lane + q;
-                        if (lc >= TP && lc < TP + STRIDE && gx + q < nx) {
-                            if (gx + q + 1 < nx) *reinterpret_cast<double2*>(dst + q) = make_double2(o.v[q], o.v[q + 1]);
-                            else dst[q] = o.v[q];
+                        for (int q = 0; q + 1 < NC; q += 2) {
+                            const int lc = NC * lane + q;
+                            if (lc >= TP && lc < TP + STRIDE && gx + q < nx) {
+                                if (gx + q + 1 < nx) *reinterpret_cast<double2*>(dst + q) = make_double2(o.v[q], o.v[q + 1]);
+                                else dst[q] = o.v[q];
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < NC; ++q) {
+                            const int lc = NC * lane + q;
+                            if (lc >= TP && lc < TP + STRIDE && gx + q < nx) dst[q] = o.v[q];
                         }
                     }
                 }
@@ -108,10 +121,9 @@ __global__ __launch_bounds__(256) void k_proto(const double* __restrict__ in, do
     }
 }
 
-template <int NC>
+template <int NC, int T>
 float run(const double* a, double* b, int nx, int ny, int pitch, int ry, Phys p, int reps) {
-    constexpr int T = 6;
-    constexpr int STRIDE = 64 * NC - 12;
+    constexpr int STRIDE = 64 * NC - 2 * (2 * ((T + 1) / 2));
     const int nstrips = (nx + STRIDE - 1) / STRIDE, nchunks = (ny + ry - 1) / ry, ntiles = nstrips * nchunks;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int r = 0; r < 300; ++r) hipLaunchKernelGGL((k_proto<NC, T>), dim3((ntiles + 3) / 4), dim3(256), 0, 0, a, b, nx, ny, pitch, ry, nstrips, ntiles, p);
@@ -126,7 +138,7 @@ float run(const double* a, double* b, int nx, int ny, int pitch, int ry, Phys p,
 int main(int argc, char** argv) {
     const int nx = argc > 1 ? atoi(argv[1]) : 16384, ny = argc > 2 ? atoi(argv[2]) : 16384;
     const int pitch = LPAD + ((nx + 1 + 255) / 256) * 256 + 256;
-    const size_t elems = static_cast<size_t>(ny + 12) * pitch;
+    const size_t elems = static_cast<size_t>(ny + 24) * pitch;
     std::vector<double> h(elems);
     srand(1);
     for (auto& v : h) v = rand() / double(RAND_MAX);
@@ -135,23 +147,41 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(a, h.data(), elems * 8, hipMemcpyHostToDevice));
     CK(hipMemset(b2, 0, elems * 8)); CK(hipMemset(b4, 0, elems * 8));
     Phys p{0.1 * 0.05, -0.1, 0.5, 0.25};
-    const double* va = a + 5 * static_cast<size_t>(pitch);
-    double* v2 = b2 + 5 * static_cast<size_t>(pitch);
-    double* v4 = b4 + 5 * static_cast<size_t>(pitch);
-    for (int ry : {62, 92, 122, 158}) {
-        const float t2 = run<2>(va, v2, nx, ny, pitch, ry, p, 200);
-        const float t4 = run<4>(va, v4, nx, ny, pitch, ry, p, 200);
-        printf("%dx%d ry=%d  NC=2: %.4f ms (%.0f Mcell/s)   NC=4: %.4f ms (%.0f Mcell/s)\n", nx, ny, ry, t2,
-               double(nx) * ny * 6 / t2 / 1e3, t4, double(nx) * ny * 6 / t4 / 1e3);
+    const double* va = a + 8 * static_cast<size_t>(pitch);
+    double* v2 = b2 + 8 * static_cast<size_t>(pitch);
+    double* v4 = b4 + 8 * static_cast<size_t>(pitch);
+    double *b3;
+    CK(hipMalloc(&b3, elems * 8)); CK(hipMemset(b3, 0, elems * 8));
+    double* v3 = b3 + 8 * static_cast<size_t>(pitch);
+    for (int ry : {92, 122, 158, 182, 206}) {
+        const float t26 = run<2, 6>(va, v2, nx, ny, pitch, ry + 2, p, 100);
+        const float t27 = run<2, 7>(va, v2, nx, ny, pitch, ry, p, 100);
+        const float t36 = run<3, 6>(va, v3, nx, ny, pitch, ry + 2, p, 100);
+        const float t35 = run<3, 5>(va, v3, nx, ny, pitch, ry + 4, p, 100);
+        const float t46 = run<4, 6>(va, v4, nx, ny, pitch, ry + 2, p, 100);
+        auto rate = [&](float t, int T) { return double(nx) * ny * T / t / 1e3; };
+        printf("%dx%d ry~%d  NC2T6 %.0f  NC2T7 %.0f  NC3T6 %.0f  NC3T5 %.0f  NC4T6 %.0f  Mcell/s\n", nx, ny, ry, rate(t26, 6), rate(t27, 7),
+               rate(t36, 6), rate(t35, 5), rate(t46, 6));
     }
+    run<2, 6>(va, v2, nx, ny, pitch, 122, p, 1); run<3, 6>(va, v3, nx, ny, pitch, 122, p, 1); run<4, 6>(va, v4, nx, ny, pitch, 122, p, 1);
+    CK(hipDeviceSynchronize());
     std::vector<double> r2(elems), r4(elems);
     CK(hipMemcpy(r2.data(), b2, elems * 8, hipMemcpyDeviceToHost));
     CK(hipMemcpy(r4.data(), b4, elems * 8, hipMemcpyDeviceToHost));
+    std::vector<double> r3(elems);
+    CK(hipMemcpy(r3.data(), b3, elems * 8, hipMemcpyDeviceToHost));
+    size_t bad3 = 0;
+    for (int j = 12; j < ny - 12; ++j)
+        for (int i = 12; i < nx - 12; ++i) {
+            const size_t o = static_cast<size_t>(j + 8) * pitch + LPAD + i;
+            bad3 += r2[o] != r3[o];
+        }
+    printf("NC=2 vs NC=3 mismatches away from the edges: %zu\n", bad3);
     size_t bad = 0;
     // interior away from the edges (the prototype has no boundary rules)
     for (int j = 12; j < ny - 12; ++j)
         for (int i = 12; i < nx - 12; ++i) {
-            const size_t o = static_cast<size_t>(j + 5) * pitch + LPAD + i;
+            const size_t o = static_cast<size_t>(j + 8) * pitch + LPAD + i;
             bad += r2[o] != r4[o];
         }
     printf("NC=2 vs NC=4 mismatches away from the edges: %zu\n", bad);
