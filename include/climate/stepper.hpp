@@ -154,6 +154,13 @@ class Stepper {
         check(csim_stepper_sum(h_, &s));
         return s;
     }
+    // bit-identity in one number: position-weighted 64-bit checksum of the local interior; the values of all ranks of a
+    // decomposition add up (mod 2^64) to the checksum of the same global field on one rank (csim_stepper_checksum)
+    unsigned long long checksum() {
+        unsigned long long v = 0;
+        check(csim_stepper_checksum(h_, &v));
+        return v;
+    }
     csim_stepper* handle() { return h_; }
 
   private:
