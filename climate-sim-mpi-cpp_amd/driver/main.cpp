@@ -4,11 +4,13 @@
 // parses `timing: total_max=`), same snapshot cadence and file (outputs/snapshots.nc holds the
 // state BEFORE step n for every n % out_every == 0; the final state is not written — SURVEY Q6).
 // Between snapshots the field never leaves HBM: stepper.run(k) advances k steps without host
-// syncs.  Extensions (flags the reference ignores): --no-output, --device-ic, --halo=mpi|rccl,
-// and ic.mode=file (the reference throws for it).
+// syncs.  Extensions (flags the reference ignores): --no-output, --device-ic, --halo=mpi|rccl, --checksum (prints the
+// position-weighted 64-bit checksum of the final global field: the same number on any process grid), and ic.mode=file
+// (the reference throws for it).
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <filesystem>
 #include <iostream>
@@ -79,6 +81,17 @@ double reduce_max(double v) {
 #endif
 }
 
+// wrap-around sum over the ranks: the per-rank checksums of a decomposed field add up to the single-rank value
+unsigned long long reduce_sum_u64(unsigned long long v) {
+#ifdef CSIM_WITH_MPI
+    unsigned long long r = 0;
+    MPI_Reduce(&v, &r, 1, MPI_UNSIGNED_LONG_LONG, MPI_SUM, 0, MPI_COMM_WORLD);
+    return r;
+#else
+    return v;
+#endif
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -125,6 +138,7 @@ int main(int argc, char** argv) {
     const bool no_output = has_flag(args, "--no-output");
     const bool device_ic = has_flag(args, "--device-ic");
     const bool halo_mpi = has_flag(args, "--halo=mpi");
+    const bool want_checksum = has_flag(args, "--checksum");
     (void)halo_mpi;
 
     climate::Stepper st(dec, cfg.bc, cfg.dx, cfg.dy, 0.0);
@@ -199,6 +213,14 @@ int main(int argc, char** argv) {
                   << cells * 16.0 / total_max / 1e9 << " GB/s algorithmic (16 B/cell-update), "
                   << cells * 16.0 / total_max / 8e12 * 100.0 << " % of 8 TB/s HBM peak, ranks=" << world_size
                   << " dims=" << dec.dims[0] << "x" << dec.dims[1] << "\n";
+    }
+    if (want_checksum) {
+        const unsigned long long cs = reduce_sum_u64(st.checksum());
+        if (world_rank == 0) {
+            char buf[32];
+            std::snprintf(buf, sizeof buf, "0x%016llx", cs);
+            std::cout << "checksum: " << buf << " (final field, interior; independent of the process grid)\n";
+        }
     }
     dec.finalize();
 #ifdef CSIM_WITH_MPI

@@ -72,10 +72,20 @@ def test_driver_mpi_four_ranks_one_gpu(tmp_path):
         pytest.skip("MPI flavour not built")
     z, m = golden("run_dev_yaml_small")
     out, h = run_driver(tmp_path, "climate_sim_hip_mpi", m, m["steps"] + 1, m["steps"],
-                        launcher=(MPIRUN, "-np", "4"), extra=("--halo=mpi",))
+                        launcher=(MPIRUN, "-np", "4"), extra=("--halo=mpi", "--checksum"))
     rec = records(h, m)
     assert np.array_equal(rec[0], z["u0"]) and np.array_equal(rec[1], z["u_final"])
     assert "dims=2x2" in out
+    # --checksum: the four ranks' position-weighted checksums add up (MPI_SUM, mod 2^64) to the value of the global field
+    import re
+    from __graft_entry__ import load_package
+    got = int(re.search(r"checksum: (0x[0-9a-f]{16})", out).group(1), 16)
+    # (the driver ran steps + 1 steps so that the record of step `steps` exists: the oracle takes the one more step)
+    from oracle import cpu_oracle as ora
+    last = np.zeros((m["ny"] + 2, m["nx"] + 2))
+    last[1:-1, 1:-1] = z["u_final"]
+    ora.run_single(last, m["dx"], m["dy"], m["D"], m["vx"], m["vy"], float(z["dt_effective"]), ora.bc_codes(m["bc"]), 1)
+    assert got == load_package().checksum_host(last[1:-1, 1:-1])
 
 
 def test_driver_ic_from_netcdf_file(tmp_path):
