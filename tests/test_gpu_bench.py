@@ -78,7 +78,7 @@ def test_bench_stalled_schedule_still_yields_a_line():
     """a schedule that never comes back (test knob: schedule 3 hangs when its turn comes) must not cost the line: the
     watchdog prints it from the schedules already timed — the conservative one first — and the process leaves with
     status 3"""
-    r = run_bench([], env={"CSIM_BENCH_SELF_TORUS": "1", "CSIM_BENCH_INJECT_STALL": "3", "CSIM_BENCH_PHASE_TIMEOUT": "3"},
+    r = run_bench([], env={"CSIM_BENCH_SELF_TORUS": "1", "CSIM_BENCH_INJECT_STALL": "3", "CSIM_BENCH_PHASE_TIMEOUT": "3", "CSIM_BENCH_DEADLINE_SCALE": "0.1"},
                   expect_rc=3)
     cfg = r["config"]
     assert r["value"] > 0 and r["n_gpus"] == 1
