@@ -80,3 +80,38 @@ def test_a_hang_in_the_very_first_exchange_leaves_the_safety_net_region():
     cfg = line["config"]
     assert cfg["halo_transport"].startswith("gloo (host-staged): the SAFETY-NET region")
     assert "overlap-0" in cfg["stalled_schedule"]["phase"] and line["value"] > 0
+
+
+def test_under_the_drivers_own_launcher_the_line_survives_a_stalled_rank(tmp_path):
+    """the exact launch line of the driver (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...): rank 1 hangs under schedule 3, rank 0's watchdog prints the line and
+    leaves, the launcher then terminates rank 1 (SIGTERM, taken by its watchdog) and reports failure — with the one JSON
+    line on its stdout"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = str(s.getsockname()[1])
+    s.close()
+    env = dict(os.environ, OMP_NUM_THREADS="1", MOCK_STALL_RANK="1", MOCK_STALL_SCHEDULE="3", CSIM_BENCH_PHASE_TIMEOUT="3",
+               CSIM_BENCH_DEADLINE_SCALE="0.1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", port, RUNNER, "--gpus", "2", "--steps", "20", "--warmup", "5", "--ramp-seconds", "0.01",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=400, env=env, cwd=tmp_path)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert p.returncode != 0 and len(lines) == 1, (p.returncode, p.stdout[-1000:], p.stderr[-1500:])
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and "overlap-3" in line["config"]["stalled_schedule"]["phase"]
+
+
+def test_under_the_drivers_own_launcher_a_complete_run(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = str(s.getsockname()[1])
+    s.close()
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+                        "--master-port", port, RUNNER, "--gpus", "4", "--steps", "20", "--warmup", "5", "--ramp-seconds", "0.01",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=400, env=dict(os.environ, OMP_NUM_THREADS="1"),
+                       cwd=tmp_path)
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert p.returncode == 0 and len(lines) == 1 and lines[0].startswith('{"metric"'), (p.returncode, p.stdout[-1000:], p.stderr[-1500:])
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 4 and line["config"]["parity_preflight"]["ok"] and line["config"]["stalled_schedule"] is None
