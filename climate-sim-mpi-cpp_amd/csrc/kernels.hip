@@ -397,8 +397,9 @@ struct OverlapGeom {
 // included) and the caller then repeats the tile with the plain form — same loads, same stores, the reference's
 // own operations.  Cost: two compares per lane and loaded row against 2 T multiplies saved.
 //
-// The EDGE body (wavefronts whose strip or chunk touches a physical edge, and the frame tiles of a final pass) is
-// the interior body plus PATCHES that put the boundary rule where a level's ghost cells come out.  Every patch sits
+// The EDGE bodies (wavefronts whose strip or chunk touches a physical edge, and the frame tiles of a final pass) are
+// the interior body plus PATCHES that put the boundary rule where a level's ghost cells come out.  In the GENERIC
+// flavour (M_GENERIC below; the straight-line flavours 0..6 compile their one patch in) every patch sits
 // in a wave-uniform branch and works on values made opaque INSIDE that branch (pin / pin2: an empty asm the value
 // passes through), so that the compiler can neither hoist the patch's moves, lane shifts and selects out of the
 // branch nor turn the branch into per-lane selects executed by every level-row — which is what it did to the
