@@ -66,7 +66,9 @@ def test_one_rank_hanging_under_a_later_schedule_still_yields_the_line():
     """rank 2 never returns from its first run() under schedule 3: ranks 0, 1, 3 then wait in a collective; every
     watchdog fires (rank 0 first), the line is built from the schedules already timed, all ranks leave with status 3"""
     rcs, line, outs = run(4, env={"MOCK_STALL_RANK": "2", "MOCK_STALL_SCHEDULE": "3", "CSIM_BENCH_PHASE_TIMEOUT": "3", "CSIM_BENCH_DEADLINE_SCALE": "0.1"})
-    assert rcs == [3] * 4 and line is not None, [o[1][-500:] for o in outs]
+    # (rank 0 leaves with the watchdog's status; the others either through their own watchdog or through gloo noticing that
+    # rank 0 is gone: non-zero either way)
+    assert rcs[0] == 3 and all(rcs) and line is not None, (rcs, [o[1][-500:] for o in outs])
     cfg = line["config"]
     assert "overlap-3" in cfg["stalled_schedule"]["phase"] and "best COMPLETED" in cfg["value_is"]
     timed = {k: v for k, v in cfg["exchange_schedules_ms_per_step"].items() if isinstance(v, float)}
@@ -76,7 +78,7 @@ def test_one_rank_hanging_under_a_later_schedule_still_yields_the_line():
 
 def test_a_hang_in_the_very_first_exchange_leaves_the_safety_net_region():
     rcs, line, outs = run(2, env={"MOCK_STALL_RANK": "1", "MOCK_STALL_SCHEDULE": "0", "CSIM_BENCH_PHASE_TIMEOUT": "3", "CSIM_BENCH_DEADLINE_SCALE": "0.1"}, timeout=400)
-    assert rcs == [3, 3] and line is not None, [o[1][-500:] for o in outs]
+    assert rcs[0] == 3 and all(rcs) and line is not None, (rcs, [o[1][-500:] for o in outs])
     cfg = line["config"]
     assert cfg["halo_transport"].startswith("gloo (host-staged): the SAFETY-NET region")
     assert "overlap-0" in cfg["stalled_schedule"]["phase"] and line["value"] > 0
