@@ -20,6 +20,9 @@ def main():
     ap.add_argument("--run", type=int, default=0, help="steps per csim_stepper_run call (0 = all of --steps in one call)")
     ap.add_argument("--modes", nargs="+", default=["single", "torus-auto", "torus-merged", "torus-bulkfirst",
                                                    "torus-overlap", "torus-serial"])
+    ap.add_argument("--links", default="1111", help="which sides (left right bottom top) are linked to the rank itself; the others are "
+                                                    "physical edges — e.g. 1100 = the mid-x tile of a 4 x 1 row, 1101 = a mid-x tile of the 4 x 2 grid")
+    ap.add_argument("--bc", default="dddd")
     args = ap.parse_args()
     csim = load_package()
     csim.lib()
@@ -30,8 +33,8 @@ def main():
             d = csim.decomp_init(1, 0, nx, ny)
             if not mode.startswith("single"):
                 for k in range(4):
-                    d.nbr[k] = 0
-            st = csim.Stepper(d, 1.0, 1.0, csim.bc_codes("dddd"))
+                    d.nbr[k] = 0 if args.links[k] == "1" else csim.NO_NEIGHBOR
+            st = csim.Stepper(d, 1.0, 1.0, csim.bc_codes(args.bc))
             if mode.startswith("single"):
                 for tok in mode.split("+")[1:]:
                     k, v = tok.split("=")
@@ -58,7 +61,7 @@ def main():
                 st.sync()
                 best = min(best, time.perf_counter() - t0)
             st.close()
-            print(json.dumps(dict(tile=sh, mode=mode, steps_per_run=args.run or args.steps, ms_per_step=best / args.steps * 1e3,
+            print(json.dumps(dict(tile=sh, mode=mode, links=args.links, bc=args.bc, steps_per_run=args.run or args.steps, ms_per_step=best / args.steps * 1e3,
                                   mcells=nx * ny * args.steps / best / 1e6)), flush=True)
 
 
