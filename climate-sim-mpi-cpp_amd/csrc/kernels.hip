@@ -829,6 +829,20 @@ hipError_t sweepO_div(const double* in, double* out, int nx, int ny, int pitch, 
     hf += (6 - (hf + 2 * (T - 1)) % 6) % 6;
     const int nright = (nx - (nstrips - 1) * STRIDE >= MAX_FUSE) ? 1 : 2;
     const bool split = ny >= 2 * hf + 1 && nstrips >= nright + 2;
+    // A band along a PHYSICAL bottom / top edge runs the generic edge body (ghost rows), about twice as slow per
+    // iteration as the other frame tiles, and the frame launch lasts as long as its slowest tile (47 us instead of 34 on
+    // a 4096 x 8192 tile with one physical side): such a band is only as high as the ghost rows require (T-1 rows,
+    // rounded so that its march is whole groups of six: 18 iterations at T = 7 instead of 24).  The tiles above it then
+    // start at row T and read the ghost row itself as level-0 input — in a bulk-first pass BEFORE this pass's ghost
+    // fill has run: fine for Dirichlet and Periodic sides, whose ghost ring never changes, not for Neumann ones, which
+    // keep the band of hf >= T rows.
+    int hphys = T - 1;
+    hphys += (6 - (hphys + 2 * (T - 1)) % 6) % 6;
+    auto thin = [&](int side) {
+        return SPECIALISE_EDGES<DIV, T>::value && bc.kind[side] != 3 && bc.kind[side] != CSIM_BC_NEUMANN;
+    };
+    const int hfb = thin(CSIM_BOTTOM) ? std::min(hf, hphys) : hf;
+    const int hft = thin(CSIM_TOP) ? std::min(hf, hphys) : hf;
     Tiling tl{};
     auto add = [&](int strip0, int nstrip, int j0, int j1, int rows) {
         if (nstrip <= 0 || j1 < j0) return;
@@ -878,12 +892,12 @@ hipError_t sweepO_div(const double* in, double* out, int nx, int ny, int pitch, 
         if (band_t) add(0, nstrips, ny - hb + 1, ny, hb);
         tail_tiles += tl.ntiles - before;
     } else if (part == 1 || part == 3) {
-        add(0, nstrips, 1, hf, hf);
-        add(0, nstrips, ny - hf + 1, ny, hf);
+        add(0, nstrips, 1, hfb, hfb);
+        add(0, nstrips, ny - hft + 1, ny, hft);
         int hs = hf;  // side strips: taller chunks waste fewer warm-up rows (2 (T - 1) per chunk) but finish later
         if (cfg.frame_rows >= MAX_FUSE) hs = cfg.frame_rows + (6 - (cfg.frame_rows + 2 * (T - 1)) % 6) % 6;
-        add(0, 1, hf + 1, ny - hf, hs);
-        add(nstrips - nright, nright, hf + 1, ny - hf, hs);
+        add(0, 1, hfb + 1, ny - hft, hs);
+        add(nstrips - nright, nright, hfb + 1, ny - hft, hs);
     }
     int nblocks;
     if (part == 3 && split) {  // merged launch: the frame tiles above, then the bulk in the same grid
@@ -891,7 +905,7 @@ hipError_t sweepO_div(const double* in, double* out, int nx, int ny, int pitch, 
         tl.frame_blocks = cdiv(tl.ntiles, 4);
         fs.nframe = static_cast<unsigned>(tl.frame_tiles);
         const int before = tl.ntiles;
-        tail_tiles = add_rows(1, nstrips - 1 - nright, hf + 1, ny - hf, std::min(ry, ny - 2 * hf));
+        tail_tiles = add_rows(1, nstrips - 1 - nright, hfb + 1, ny - hft, std::min(ry, ny - hfb - hft));
         nblocks = tl.frame_blocks + cdiv(tl.ntiles - before, 4);
     } else if (part == 3) {  // a tile that is all frame: every tile counts for the flag
         tl.frame_tiles = tl.ntiles;
@@ -901,7 +915,7 @@ hipError_t sweepO_div(const double* in, double* out, int nx, int ny, int pitch, 
         fs.nframe = static_cast<unsigned>(tl.frame_tiles);
         nblocks = tl.frame_blocks;
     } else {
-        if (part == 2 && split) tail_tiles = add_rows(1, nstrips - 1 - nright, hf + 1, ny - hf, std::min(ry, ny - 2 * hf));
+        if (part == 2 && split) tail_tiles = add_rows(1, nstrips - 1 - nright, hfb + 1, ny - hft, std::min(ry, ny - hfb - hft));
         if (tl.ntiles == 0) return hipSuccess;  // part 2 of a field that is all frame
         nblocks = cdiv(tl.ntiles, 4);
         fs = FrameSync{};

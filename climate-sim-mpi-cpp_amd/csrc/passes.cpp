@@ -490,6 +490,16 @@ int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy,
     // 4096 x 8192 1.26-1.27 M against 1.11-1.19 M merged, 8192 x 16384 1.49-1.50 M against 1.45 M, 8192^2 equal), and
     // it needs nothing but stream order and events: no in-kernel flag, no hipStreamWaitValue64, no write-through stores.
     s->bulk_first_run = s->multi && !s->external && (s->overlap == 4 || s->overlap == 5);
+    if (s->bulk_first_run && !s->phys_ring_filled) {
+        // A bulk-first pass launches its bulk before its own ghost fill; the bulk tiles next to a thin band along a
+        // physical Dirichlet / Periodic side (sweepO_div) read that side's ghost line as level-0 input, which never changes
+        // — once it has been written: after an upload or an initialisation that is now (physical sides only, both
+        // buffers; the halo-dependent corners and every later refresh are the passes' own ghost fills).
+        GhostArgs gp = ghost_args(s);
+        for (int k = 0; k < 4; ++k) gp.recv[k] = nullptr;
+        CSIM_HIP(launch_ghost_fill(s->cur, s->nxt, s->nx, s->ny, s->pitch, gp, s->tail ? s->tail : s->s_comp));
+        s->phys_ring_filled = true;
+    }
     for (long k = 0; k < plan.size(); ++k) {
         const int t = plan.at(k);
         int rc;

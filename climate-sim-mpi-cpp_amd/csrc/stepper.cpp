@@ -286,6 +286,7 @@ int csim_stepper_upload(csim_stepper* s, const double* host) {
     s->halo_fresh = false;
     s->faces_depth = 0;
     s->ring_ok = false;
+    s->phys_ring_filled = false;
     return CSIM_OK;
 }
 
@@ -357,6 +358,7 @@ int csim_stepper_init_gaussian(csim_stepper* s, double A, double sigma_frac, dou
     s->halo_fresh = false;
     s->faces_depth = 0;
     s->ring_ok = false;
+    s->phys_ring_filled = false;
     return CSIM_OK;
 }
 

@@ -101,6 +101,8 @@ struct csim_stepper {
                             // 3: frame and bulk in ONE launch (needs signal memory, else as 1);
                             // 4: bulk launch first, hiding THIS pass's exchange, then the frame (pass_fused_bulk_first);
                             // 5 (default): as 4 (until round 3: 4 on runs of fewer than 16 passes, 3 otherwise)
+    bool phys_ring_filled = false;  // several ranks: the ghost lines of the PHYSICAL sides have been filled in both buffers since the
+                                    // last upload / initialisation (bulk-first passes read constant Dirichlet ghosts before their own fill)
     bool ring_ok = false;      // single rank without a Neumann side: the ghost ring (Dirichlet value / untouched
                                // Periodic ghosts) is constant and both buffers already hold it — no more ghost fills
     bool pre_unpacked = false; // the comm stream already unpacked the faces in recv2[] and filled the ghosts

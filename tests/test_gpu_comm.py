@@ -429,3 +429,33 @@ def test_borrowed_communicator_runs_a_second_stepper(csim):
     big.run(D, dt, vx, vy, 2)
     big.sync()
     big.close()
+
+
+@pytest.mark.parametrize("bc", ["ddnd", "dddn", "dddd", "ddpp", "ddpn", "dddp"])
+def test_physical_bottom_and_top_next_to_linked_sides_every_depth_and_schedule(csim, bc):
+    """A tile like the mid-x tiles of the 4 x 2 grid: left / right neighbours, PHYSICAL bottom / top.  Its frame holds
+    thin generic bands along Dirichlet / Periodic sides (T-1 rows: the tiles above start at row T and read the ghost
+    line as level-0 input — in a bulk-first pass before that pass's own ghost fill, hence the one-off fill of the
+    physical ghost lines at the start of a run) and full-height bands along Neumann sides.  Uploaded ghost lines are
+    random: Periodic sides must keep them, Dirichlet / Neumann sides must overwrite them before anything reads them."""
+    nx, ny = 1024, 300
+    D, vx, vy, dt = 0.05, 0.5, -0.25, 0.1
+    rng = np.random.default_rng(31)
+    u0 = np.zeros((ny + 2, nx + 2))
+    u0[1:-1, 1:-1] = rng.standard_normal((ny, nx))
+    u0[0, :] = rng.standard_normal(nx + 2)
+    u0[-1, :] = rng.standard_normal(nx + 2)
+    sides, codes = (1, 1, 0, 0), csim.bc_codes(bc)
+    mask = CORNERLESS(ny, nx)
+    for steps, fuse in ((7, 7), (5, 5), (6, 6), (4, 4), (20, -1)):
+        want = torus_oracle(u0, 1.0, 1.0, D, vx, vy, dt, steps, sides, codes)
+        for overlap in (4, 3, 1):
+            st = csim.Stepper(self_neighbor_decomp(csim, nx, ny, sides), 1.0, 1.0, codes)
+            st.comm_init(csim.comm_unique_id())
+            st.set_option("overlap", overlap)
+            st.set_option("fuse", fuse)
+            st.upload(u0)
+            st.run(D, dt, vx, vy, steps)
+            got = st.download()
+            st.close()
+            assert np.array_equal(got[mask], want[mask]), (bc, steps, fuse, overlap, int((got[mask] != want[mask]).sum()))

@@ -15,10 +15,11 @@ csim = load_package()
 csim.lib()
 csim.set_device(0)
 d = csim.decomp_init(1, 0, nx, ny)
+links = os.environ.get("LINKS", "1111")   # which sides (left right bottom top) are linked to the rank itself
 if mode != "single":
     for k in range(4):
-        d.nbr[k] = 0
-st = csim.Stepper(d, 1.0, 1.0, csim.bc_codes("dddd"))
+        d.nbr[k] = 0 if links[k] == "1" else csim.NO_NEIGHBOR
+st = csim.Stepper(d, 1.0, 1.0, csim.bc_codes(os.environ.get("BC", "dddd")))
 if mode != "single":
     st.comm_init(csim.comm_unique_id())
     st.set_option("overlap", {"torus-overlap": 1, "torus-serial": 0, "torus-merged": 3, "torus-bulkfirst": 4, "torus-auto": 5}[mode])
