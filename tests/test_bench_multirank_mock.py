@@ -6,21 +6,19 @@ wrong tiles being excluded; a rank that hangs under one schedule — the other r
 with the watchdogs' line and status 3; the same under the very first schedule ending with the safety-net region."""
 import json
 import os
-import socket
 import subprocess
 import sys
 
 import pytest
+
+from ports import rendezvous_port
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RUNNER = os.path.join(ROOT, "tests", "bench_mock_runner.py")
 
 
 def run(world, env=None, timeout=300):
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = str(s.getsockname()[1])
-    s.close()
+    port = str(rendezvous_port())
     procs = []
     for r in range(world):
         e = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
@@ -89,10 +87,7 @@ def test_under_the_drivers_own_launcher_the_line_survives_a_stalled_rank(tmp_pat
     127.0.0.1 --master-port P bench.py --gpus N ...): rank 1 hangs under schedule 3, rank 0's watchdog prints the line and
     leaves, the launcher then terminates rank 1 (SIGTERM, taken by its watchdog) and reports failure — with the one JSON
     line on its stdout"""
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = str(s.getsockname()[1])
-    s.close()
+    port = str(rendezvous_port())
     env = dict(os.environ, OMP_NUM_THREADS="1", MOCK_STALL_RANK="1", MOCK_STALL_SCHEDULE="3", CSIM_BENCH_PHASE_TIMEOUT="3",
                CSIM_BENCH_DEADLINE_SCALE="0.1")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
@@ -105,10 +100,7 @@ def test_under_the_drivers_own_launcher_the_line_survives_a_stalled_rank(tmp_pat
 
 
 def test_under_the_drivers_own_launcher_a_complete_run(tmp_path):
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = str(s.getsockname()[1])
-    s.close()
+    port = str(rendezvous_port())
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
                         "--master-port", port, RUNNER, "--gpus", "4", "--steps", "20", "--warmup", "5", "--ramp-seconds", "0.01",
                         "--no-cpu-baseline"], capture_output=True, text=True, timeout=400, env=dict(os.environ, OMP_NUM_THREADS="1"),

@@ -8,6 +8,8 @@ import sys
 
 import pytest
 
+from ports import rendezvous_port
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -123,11 +125,7 @@ def test_bench_two_ranks_host_staged_fallback(forced):
     built.  forced: CSIM_BENCH_HALO=gloo asks for it; not forced: the run first times its host-staged SAFETY-NET region,
     then really tries RCCL, which refuses two ranks on one device (ncclCommInitRank: invalid usage), and every rank
     falls back together"""
-    import socket
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = str(s.getsockname()[1])
-    s.close()
+    port = str(rendezvous_port())
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",

@@ -5,7 +5,6 @@ oracle, against the golden vectors the compiled reference produced under `mpirun
 import glob
 import json
 import os
-import socket
 import subprocess
 import sys
 
@@ -17,12 +16,7 @@ GOLDEN = os.path.join(HERE, "golden")
 WORKER = os.path.join(HERE, "multirank_worker.py")
 
 
-def free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+from ports import rendezvous_port as free_port  # noqa: E402  (below the ephemeral range: see tests/ports.py)
 
 
 def launch(world, engine, case, timeout=300):
