@@ -140,6 +140,7 @@ def lib() -> C.CDLL:
         "csim_stepper_tune": (i, [vp, d, d, d, d]),
         "csim_stepper_keep_warm": (i, [vp, d, d, d, d, d]),
         "csim_pass_schedule": (i, [i, i, C.c_long, i, ip, i, C.POINTER(C.c_long)]),
+        "csim_pass_schedule_for": (i, [i, i, C.c_long, i, i, ip, i, C.POINTER(C.c_long)]),
         "csim_stepper_sync": (i, [vp]),
         "csim_stepper_checksum": (i, [vp, C.POINTER(C.c_ulonglong)]),
         "csim_stepper_comm_share": (i, [vp, vp]),
@@ -228,12 +229,13 @@ def exchange_plan(dec: Decomp, depth: int):
             [(m.peer, m.dir, m.count) for m in recvs[:nr.value]])
 
 
-def pass_schedule(nsteps: int, smallest_tile: int = 1 << 30, fuse: int = -1, tile_cells: int = 0):
-    """time steps per HBM pass of a run of nsteps (csim_pass_schedule), as a list"""
+def pass_schedule(nsteps: int, smallest_tile: int = 1 << 30, fuse: int = -1, tile_cells: int = 0, diffusion_only: bool = False):
+    """time steps per HBM pass of a run of nsteps (csim_pass_schedule_for), as a list"""
     n = C.c_long(0)
-    _ck(lib().csim_pass_schedule(nsteps, min(smallest_tile, 1 << 30), tile_cells, fuse, None, 0, C.byref(n)))
+    args = (nsteps, min(smallest_tile, 1 << 30), tile_cells, fuse, int(diffusion_only))
+    _ck(lib().csim_pass_schedule_for(*args, None, 0, C.byref(n)))
     buf = (C.c_int * max(1, n.value))()
-    _ck(lib().csim_pass_schedule(nsteps, min(smallest_tile, 1 << 30), tile_cells, fuse, buf, n.value, C.byref(n)))
+    _ck(lib().csim_pass_schedule_for(*args, buf, n.value, C.byref(n)))
     return list(buf[:n.value])
 
 

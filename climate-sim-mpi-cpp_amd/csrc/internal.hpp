@@ -110,7 +110,10 @@ constexpr int MAX_FUSE = 7;       // deepest temporal blocking (123 VGPRs: still
 // decides (+17...22 % over 6 at 512^2, 1024^2, 3072^2)
 constexpr long BIG_TILE_CELLS = 200000000L;
 constexpr long SMALL_TILE_CELLS = 12000000L;
-inline int pref_fuse(long tile_cells) {
+// `still` — the diffusion-only flavour (v == 0: half the arithmetic, so the sweep is HBM-bound and every extra level
+// per pass pays): 7 at every size (profiles/r03_diffusion_only_depth.jsonl: +8 % over 6 at 4096^2, +13 % at 8192^2 and 16384^2)
+inline int pref_fuse(long tile_cells, bool still = false) {
+    if (still) return 7;
     return tile_cells >= BIG_TILE_CELLS ? 7 : (tile_cells > 0 && tile_cells < SMALL_TILE_CELLS) ? 4 : 6;
 }
 constexpr int GHOST_EXTRA = 6;    // device-only ghost layers beyond the reference's one (= MAX_FUSE-1)

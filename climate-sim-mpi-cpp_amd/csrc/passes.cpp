@@ -392,16 +392,27 @@ int tune_rows(csim_stepper* s, const Phys& p, int T, bool preferred_depth) {
 
 }  // namespace csim
 
+// Which arithmetic flavour of the multi-step sweep these parameters select (read-only options "fused_2c_active",
+// "diffusion_only_active").  v == 0: the screened interior body drops the advection term (kernels.hip, cell) — another
+// balance of arithmetic against HBM traffic, so the chunk heights found for the other flavour are not carried over.
+static void note_flavour(csim_stepper* s, const Phys& p) {
+    s->fused_2c_active = p.fast_thr > 0.0 && p.div_mode != 3;
+    const int still = s->fused_2c_active && p.div_mode <= 1 && p.vx == 0.0 && p.vy == 0.0;
+    if (still != s->diffusion_only_active) s->forget_tuning();
+    s->diffusion_only_active = still;
+}
+
 extern "C" {
 
 // the one-off trial of csim_stepper_run's first long call, on request (e.g. before a timed loop)
 int csim_stepper_tune(csim_stepper* s, double D, double dt, double vx, double vy) {
     CSIM_REQUIRE(s, "null stepper");
     CSIM_SETTLE(s);
-    const int depth = fused_depth(s);
-    if (depth < 2 || s->cfg.rows_per_chunk != 0) return CSIM_OK;
     Phys p = make_phys(s->dx, s->dy, D, dt, vx, vy, s->contract != 0);
     if (!s->fused_2c) p.fast_thr = 0.0;
+    note_flavour(s, p);
+    const int depth = fused_depth(s);
+    if (depth < 2 || s->cfg.rows_per_chunk != 0) return CSIM_OK;
     if (!s->tuned) {
         int rc = tune_rows(s, p, depth);
         if (rc) return rc;
@@ -426,10 +437,11 @@ int csim_stepper_keep_warm(csim_stepper* s, double D, double dt, double vx, doub
     CSIM_SETTLE(s);
     const auto t0 = std::chrono::steady_clock::now();
     auto elapsed = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
-    const int depth = fused_depth(s);
-    if (depth < 2) return CSIM_OK;
     Phys p = make_phys(s->dx, s->dy, D, dt, vx, vy, s->contract != 0);
     if (!s->fused_2c) p.fast_thr = 0.0;
+    note_flavour(s, p);
+    const int depth = fused_depth(s);
+    if (depth < 2) return CSIM_OK;
     int kind[4];
     for (int k = 0; k < 4; ++k) kind[k] = s->phys[k] ? s->bc[k] : 3;
     CSIM_HIP(hipStreamSynchronize(s->s_comm));
@@ -448,6 +460,9 @@ int csim_stepper_keep_warm(csim_stepper* s, double D, double dt, double vx, doub
 int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy, int nsteps) {
     CSIM_REQUIRE(s, "null stepper");
     CSIM_REQUIRE(nsteps >= 0, "nsteps must be >= 0");
+    Phys p = make_phys(s->dx, s->dy, D, dt, vx, vy, s->contract != 0);
+    if (!s->fused_2c) p.fast_thr = 0.0;
+    note_flavour(s, p);  // before the depth: the diffusion-only flavour prefers 7 steps per pass at every size
     // Up to MAX_FUSE steps per HBM pass where possible (across ranks: a tile at least as large as
     // the face depth).
     const int depth = fused_depth(s);
@@ -468,9 +483,6 @@ int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy,
     if (!s->external && (s->faces_depth != 0 || s->pre_unpacked))
         return fail(CSIM_ERR_STATE, "internal: csim_stepper_run entered with faces of a fused pass in flight "
                                     "(an earlier call failed half-way?): upload or re-initialise the field");
-    Phys p = make_phys(s->dx, s->dy, D, dt, vx, vy, s->contract != 0);
-    if (!s->fused_2c) p.fast_thr = 0.0;
-    s->fused_2c_active = p.fast_thr > 0.0 && p.div_mode != 3;
     const GhostArgs g = ghost_args(s);
     if (s->multi && s->external && nsteps >= 2) return pass_fused(s, p, nsteps, 0);
     // The ghost ring left in the field must be exactly the reference's: the halos / boundary values
@@ -483,7 +495,7 @@ int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy,
         if (rc) return rc;
     }
     PassPlan plan;
-    plan_passes(nsteps, cap, !auto_depth, s->tile_cells, plan);
+    plan_passes(nsteps, cap, !auto_depth, s->tile_cells, plan, s->diffusion_only_active != 0);
     // exchange schedule of this run: bulk-first (4, and the default 5).  Until round 3 the default went bulk-first only on
     // runs of fewer than 16 passes and merged (3) otherwise; with the relay (pass_fused_bulk_first) bulk-first is the
     // faster one at every run length on every per-GPU tile of the 16384^2 run (self-linked torus, 1200-step runs:

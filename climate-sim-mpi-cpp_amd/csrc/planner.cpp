@@ -20,7 +20,11 @@ static const double STEP_COST_BIG[MAX_FUSE + 1] = {0.0, 4.52, 2.32, 1.55, 1.24, 
 static const double STEP_COST_MID[MAX_FUSE + 1] = {0.0, 4.52, 2.32, 1.55, 1.20, 1.04, 1.0, 1.005};    // 5e7 .. 2e8 (8192^2, 8192 x 16384)
 static const double STEP_COST_MIDSMALL[MAX_FUSE + 1] = {0.0, 4.0, 2.0, 1.40, 1.12, 1.0, 1.0, 1.10};   // 1.2e7 .. 5e7 (4096^2, 4096 x 8192)
 static const double STEP_COST_SMALL[MAX_FUSE + 1] = {0.0, 3.0, 1.5, 1.03, 1.0, 1.0, 1.2, 1.22};       // < 1.2e7 (relative to T = 4)
-static const double* step_cost_table(long tile_cells) {
+// diffusion-only flavour (HBM-bound): 16384^2 2.07 / 1.83 / 1.54 / 1.32 / 0.99 M cell updates per us at depths 7 .. 3,
+// 4096^2 1.59 / 1.46 / 1.29 / 1.11 / 0.83 (profiles/r03_diffusion_only_depth.jsonl), relative to T = 7
+static const double STEP_COST_STILL[MAX_FUSE + 1] = {0.0, 6.0, 3.2, 2.0, 1.5, 1.28, 1.11, 1.0};
+static const double* step_cost_table(long tile_cells, bool still) {
+    if (still) return STEP_COST_STILL;
     if (tile_cells >= BIG_TILE_CELLS) return STEP_COST_BIG;
     if (tile_cells <= 0 || tile_cells >= 50000000L) return STEP_COST_MID;  // (0 = size unknown)
     return tile_cells >= SMALL_TILE_CELLS ? STEP_COST_MIDSMALL : STEP_COST_SMALL;
@@ -29,8 +33,8 @@ static const double PASS_COST = 0.1;   // launch and inter-kernel gap, in time s
 
 namespace csim {
 
-void plan_passes(int K, int cap, bool balanced, long tile_cells, PassPlan& plan) {
-    const double* step_cost = step_cost_table(tile_cells);
+void plan_passes(int K, int cap, bool balanced, long tile_cells, PassPlan& plan, bool still) {
+    const double* step_cost = step_cost_table(tile_cells, still);
     plan = PassPlan{};
     std::vector<int>& out = plan.tail;
     if (K <= 0) return;
@@ -54,7 +58,7 @@ void plan_passes(int K, int cap, bool balanced, long tile_cells, PassPlan& plan)
         }
         return;
     }
-    const int pref = std::min(cap, pref_fuse(tile_cells));
+    const int pref = std::min(cap, pref_fuse(tile_cells, still));
     // long runs: passes of the preferred depth, the last <= 8 * pref steps are planned
     if (K > 8 * pref) plan.lead = (K - 8 * pref + pref - 1) / pref;
     plan.lead_depth = pref;
@@ -85,14 +89,20 @@ extern "C" {
 // decomposition whose smallest tile is `smallest_tile` cells deep, with option "fuse" = `fuse`
 int csim_pass_schedule(int nsteps, int smallest_tile, long tile_cells, int fuse, int* depths, int max_depths,
                        long* npasses) {
+    return csim_pass_schedule_for(nsteps, smallest_tile, tile_cells, fuse, 0, depths, max_depths, npasses);
+}
+
+int csim_pass_schedule_for(int nsteps, int smallest_tile, long tile_cells, int fuse, int diffusion_only, int* depths,
+                           int max_depths, long* npasses) {
     CSIM_REQUIRE(npasses && nsteps >= 0 && smallest_tile >= 1, "bad argument");
+    const bool still = diffusion_only != 0;
     CSIM_REQUIRE(fuse >= -1 && fuse <= MAX_FUSE, "fuse must be -1 (auto) or 0..7");
     CSIM_REQUIRE(max_depths == 0 || depths, "depths is null");
     const int fuse_cap = std::max(1, std::min(MAX_FUSE, smallest_tile));
-    const int depth = std::min(fuse < 0 ? pref_fuse(tile_cells) : fuse, fuse_cap);
+    const int depth = std::min(fuse < 0 ? pref_fuse(tile_cells, still) : fuse, fuse_cap);
     const int cap = depth < 2 ? 1 : fuse < 0 ? std::min(MAX_FUSE, fuse_cap) : depth;
     PassPlan plan;
-    plan_passes(nsteps, cap, fuse >= 0, tile_cells, plan);
+    plan_passes(nsteps, cap, fuse >= 0, tile_cells, plan, still);
     *npasses = plan.size();
     for (long k = 0; k < plan.size() && k < max_depths; ++k) depths[k] = plan.at(k);
     return CSIM_OK;

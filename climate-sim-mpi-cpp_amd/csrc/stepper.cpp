@@ -29,7 +29,7 @@ bool depth_ok(const csim_stepper* s, int depth) {
 // depth of the fused passes of this stepper with the current options (1 = single steps only): what
 // the option "fuse" asks for, or pref_fuse(tile) — the depth with the lowest cost per step — in auto mode
 int fused_depth(const csim_stepper* s) {
-    const int depth = std::min(s->fuse < 0 ? pref_fuse(s->tile_cells) : s->fuse, s->fuse_cap);
+    const int depth = std::min(s->fuse < 0 ? pref_fuse(s->tile_cells, s->diffusion_only_active != 0) : s->fuse, s->fuse_cap);
     const bool dpp_family = s->cfg.variant == VAR_AUTO || s->cfg.variant == VAR_DPP;
     return depth >= 2 && dpp_family ? depth : 1;
 }
@@ -615,6 +615,7 @@ int csim_stepper_get_option(const csim_stepper* s, const char* key, long* value)
     else if (k == "relay_events") *value = s->relay_events;
     else if (k == "fused_2c") *value = s->fused_2c;
     else if (k == "fused_2c_active") *value = s->fused_2c_active;
+    else if (k == "diffusion_only_active") *value = s->diffusion_only_active;
     else if (k == "frame_rows") *value = s->cfg.frame_rows;
     else if (k == "external_halo") *value = s->external;
     else if (k == "fuse") *value = s->fuse;

@@ -84,6 +84,7 @@ struct csim_stepper {
     int frame_fence = 0, frame_prio = 1;  // experiment switches of mode 3, see FrameSync
     int fused_2c = 1;         // k_sweepO_dpp's interior body fuses E - 2c into one fma under the overflow guard (Phys::fast_thr)
     int fused_2c_active = 0;  // read-only: whether the last run's parameters allowed it
+    int diffusion_only_active = 0;  // read-only: the last run had v == 0 and swept with the advection term left out of the screened body
     int direct_faces = 1;                 // merged launch: the frame wavefronts fill send2[] themselves (no pack kernel)
     bool bulk_first_run = false;          // the current csim_stepper_run uses pass_fused_bulk_first
     // asynchronous snapshot of the interior (device staging copy + pinned host buffer + I/O stream)
@@ -172,7 +173,7 @@ struct PassPlan {
     long size() const { return lead + static_cast<long>(tail.size()); }
     int at(long k) const { return k < lead ? lead_depth : tail[static_cast<size_t>(k - lead)]; }
 };
-void plan_passes(int K, int cap, bool balanced, long tile_cells, PassPlan& plan);
+void plan_passes(int K, int cap, bool balanced, long tile_cells, PassPlan& plan, bool still = false);
 
 // profile.cpp
 int prof_fold(csim_stepper* s);

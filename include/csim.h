@@ -177,6 +177,10 @@ int csim_stepper_run(csim_stepper* s, double D, double dt, double vx, double vy,
  * schedule without communicating. */
 int csim_pass_schedule(int nsteps, int smallest_tile, long tile_cells, int fuse, int* depths, int max_depths,
                        long* npasses);
+/* the same for a given arithmetic flavour: diffusion_only != 0 = a run with vx == vy == 0 (see option "fused_2c"), whose
+ * sweep does half the arithmetic and is HBM-bound: 7 steps per pass at every tile size (csim_pass_schedule = flavour 0) */
+int csim_pass_schedule_for(int nsteps, int smallest_tile, long tile_cells, int fuse, int diffusion_only, int* depths,
+                           int max_depths, long* npasses);
 /* optional, before a timed loop: the one-off rows-per-chunk trial that the first long
  * csim_stepper_run would otherwise do (option "autotune"), and — with automatic pass depths — a trial for every
  * other depth a pass plan may mix in (4..7; read back as "tuned_rows_4" .. "tuned_rows_7"); does not advance the field */
@@ -216,6 +220,10 @@ int csim_stepper_sum(csim_stepper* s, double* out);
  *                    sequence (bit-identical for every non-NaN cell, the same cells NaN; the reference does not define NaN
  *                    payloads).  14 instead of 15 fp64 operations per cell.  "fused_2c_active" (read-only): whether
  *                    the last run's parameters allowed it (growth bound per step, see make_phys)
+ *                    With vx == vy == 0 (diffusion only, BASELINE configs[1]) the same screened body also leaves out
+ *                    the advection term, whose value is then +-0 (7 instead of 14 operations per cell; a loaded -0
+ *                    sends the tile to the reference's sequence, because o + (+0) would turn an o of -0 into +0).
+ *                    "diffusion_only_active" (read-only): whether the last run swept that way
  *   "fuse"           time steps per HBM pass: -1 auto (the cheapest split of a run into passes of 2..7 steps, e.g.
  *                    1000 = 166 x 6 + 4, 20 = 7 + 7 + 6), 0/1 off, 2..7 balanced passes of at most that depth
  *   "variant"        single-step kernel family: 0 auto, 1 dpp, 2 lds, 3 naive

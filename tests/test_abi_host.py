@@ -110,6 +110,15 @@ def test_pass_schedule_is_a_pure_function_with_the_documented_properties():
     assert ps(1000, tile_cells=big) == [7] * 142 + [6] and ps(20, tile_cells=big) == [7, 7, 6]
     assert ps(36, tile_cells=big) == [6] * 6 and ps(35, tile_cells=big) == [7] * 5 and ps(12, tile_cells=big) == [6, 6]
     assert ps(20, tile_cells=4096 * 8192) == [5, 5, 5, 5]   # depth 7 costs 8-10 % more per step on the 8-GPU tile
+    # the diffusion-only flavour (v == 0, csim_pass_schedule_for): HBM-bound, 7 steps per pass at every tile size
+    for cells in (0, 10 ** 6, 4096 * 4096, 4096 * 8192, big):
+        assert ps(20, tile_cells=cells, diffusion_only=True) == [7, 7, 6] and ps(700, tile_cells=cells, diffusion_only=True) == [7] * 100
+        for k in list(range(0, 60)) + [997, 1001]:
+            for cap in (1, 2, 3, 5, 7, 100):
+                plan = ps(k, cap, -1, cells, True)
+                assert sum(plan) == k and all(1 <= t <= max(1, min(cap, 7)) for t in plan), (cells, k, cap, plan)
+                assert cap < 3 or k < 2 or 1 not in plan
+    assert pkg.lib().csim_pass_schedule_for(10, 1 << 30, 0, 9, 1, None, 0, ctypes.byref(n)) != 0   # fuse out of range
     assert ps(100, tile_cells=512 * 512)[:12] == [4] * 12 and ps(100, tile_cells=8192 * 8192)[:8] == [6] * 8
     with pytest.raises(pkg.CsimError):
         ps(5, 8, 9)

@@ -23,7 +23,9 @@ def main():
     ap.add_argument("--links", default="1111", help="which sides (left right bottom top) are linked to the rank itself; the others are "
                                                     "physical edges — e.g. 1100 = the mid-x tile of a 4 x 1 row, 1101 = a mid-x tile of the 4 x 2 grid")
     ap.add_argument("--bc", default="dddd")
+    ap.add_argument("--physics", default="0.05,0.1,0.5,0.25", help="D,dt,vx,vy (vx = vy = 0: the diffusion-only flavour, BASELINE configs[1])")
     args = ap.parse_args()
+    phys = tuple(float(v) for v in args.physics.split(","))
     csim = load_package()
     csim.lib()
     csim.set_device(0)
@@ -48,20 +50,20 @@ def main():
             st.init_gaussian()
             t0 = time.perf_counter()
             while time.perf_counter() - t0 < 0.3:  # leave the idle clocks (and let the stepper tune its chunking)
-                st.run(0.05, 0.1, 0.5, 0.25, 60)
+                st.run(*phys, 60)
                 st.sync()
             best = 1e9
             for _ in range(3):
                 t0 = time.perf_counter()
                 if args.run > 0:   # many short runs back to back, like a driver loop between snapshots
                     for _ in range(args.steps // args.run):
-                        st.run(0.05, 0.1, 0.5, 0.25, args.run)
+                        st.run(*phys, args.run)
                 else:
-                    st.run(0.05, 0.1, 0.5, 0.25, args.steps)
+                    st.run(*phys, args.steps)
                 st.sync()
                 best = min(best, time.perf_counter() - t0)
             st.close()
-            print(json.dumps(dict(tile=sh, mode=mode, links=args.links, bc=args.bc, steps_per_run=args.run or args.steps, ms_per_step=best / args.steps * 1e3,
+            print(json.dumps(dict(tile=sh, mode=mode, links=args.links, bc=args.bc, physics=args.physics, steps_per_run=args.run or args.steps, ms_per_step=best / args.steps * 1e3,
                                   mcells=nx * ny * args.steps / best / 1e6)), flush=True)
 
 
