@@ -23,17 +23,19 @@ def main():
     ap.add_argument("--bcs", nargs="+", default=["dddd", "nnnn"])
     ap.add_argument("--rows", type=int, nargs="+", default=[110, 134, 158, 182, 206, 230])
     ap.add_argument("--passes", type=int, default=4)
+    ap.add_argument("--physics", default="0.05,0.1,0.5,0.25", help="D,dt,vx,vy (default: bench.py PHYS; vx = vy = 0: the diffusion-only flavour)")
+    ap.add_argument("--depths", type=int, nargs="+", default=[1, 2, 3, 4, 5, 6, 7])
     args = ap.parse_args()
     csim = load_package()
     csim.lib()
     csim.set_device(0)
-    D, dt, vx, vy = 0.05, 0.1, 0.5, 0.25   # bench.py PHYS
+    D, dt, vx, vy = (float(v) for v in args.physics.split(","))
     seq = []
     for bc in args.bcs:
         st = csim.Stepper.single(args.nx, args.ny, 1.0, 1.0, csim.bc_codes(bc))
         st.set_option("autotune", 0)
         st.init_gaussian(1.0, 0.05, 0.5, 0.5)
-        cfgs = [(1, 0), (2, 0), (3, 0), (4, 0)] + [(T, r) for T in (5, 6, 7) for r in args.rows]
+        cfgs = [(T, 0) for T in (1, 2, 3, 4) if T in args.depths] + [(T, r) for T in (5, 6, 7) if T in args.depths for r in args.rows]
         for T, ry in cfgs:
             st.set_option("fuse", 0 if T == 1 else T)
             st.set_option("rows_per_chunk", ry)
