@@ -9,6 +9,7 @@
 
 #include <cstdlib>
 #include <map>
+#include <string>
 #include <vector>
 
 namespace csim {
@@ -171,6 +172,45 @@ int main(int argc, char** argv) {
                         "duration p50 %.1f p90 %.1f max %.1f, end p50 %.1f p99 %.1f max %.1f\n",
                         de.size(), pct(de, 0.5), pct(de, 0.9), pct(de, 1), pct(ee, 0.5), pct(ee, 1), di.size(), pct(di, 0.5),
                         pct(di, 0.9), pct(di, 1), pct(ei, 0.5), pct(ei, 0.99), pct(ei, 1));
+        }
+        // Who finishes first on a SIMD?  Per SIMD with exactly four working waves: their block LAYERS (block id / 256: the
+        // k-th block a CU received, if the dispatcher deals blocks round-robin) in the order they END, and in the order
+        // they START.  "0123" = the oldest ends first.
+        {
+            struct W { double start, end; int layer; };
+            std::map<unsigned long long, std::vector<W>> by_simd;
+            for (size_t w = 0; w < nwaves; ++w) {
+                const double d = (tr[3 * w + 1] - tr[3 * w]) * us;
+                if (!tr[3 * w] || d < 2.0) continue;
+                const unsigned long long id = tr[3 * w + 2];
+                const unsigned hw = static_cast<unsigned>(id), xcc = static_cast<unsigned>(id >> 32) & 0xf;
+                const unsigned long long key = (static_cast<unsigned long long>(xcc) << 16) | (((hw >> 13) & 7) << 12) |
+                                               (((hw >> 12) & 1) << 11) | (((hw >> 8) & 15) << 4) | ((hw >> 4) & 3);
+                by_simd[key].push_back({(tr[3 * w] - tmin) * us, (tr[3 * w + 1] - tmin) * us, static_cast<int>(w / 4) >> 8});
+            }
+            std::map<std::string, int> by_end, by_start;
+            for (auto& kv : by_simd) {
+                auto v = kv.second;
+                if (v.size() != 4) continue;
+                std::sort(v.begin(), v.end(), [](const W& a, const W& b) { return a.end < b.end; });
+                std::string e, st2;
+                for (auto& x : v) e += static_cast<char>('0' + std::min(x.layer, 9));
+                std::sort(v.begin(), v.end(), [](const W& a, const W& b) { return a.start < b.start; });
+                for (auto& x : v) st2 += static_cast<char>('0' + std::min(x.layer, 9));
+                by_end[e] += 1;
+                by_start[st2] += 1;
+            }
+            auto top = [](std::map<std::string, int>& m) {
+                std::vector<std::pair<int, std::string>> v;
+                for (auto& kv : m) v.push_back({kv.second, kv.first});
+                std::sort(v.rbegin(), v.rend());
+                for (size_t i = 0; i < v.size() && i < 8; ++i) std::printf(" %s:%d", v[i].second.c_str(), v[i].first);
+            };
+            std::printf("  block layers of a SIMD's four waves in END order:");
+            top(by_end);
+            std::printf("\n  ... in START order:");
+            top(by_start);
+            std::printf("\n");
         }
         // concurrency over time: how many working waves are alive in each 10 % slice of the launch
         const double span = (tmax - tmin) * us;
