@@ -184,6 +184,11 @@ def kernel_label(T):
     return "k_sweep_dpp" if T == 1 else f"k_sweepO_dpp<T={T}>"
 
 
+def diffusion_only():
+    """vx = vy = 0: the multi-step sweep runs its seven-operation flavour (csim.h, option "fused_2c")"""
+    return PHYS["vx"] == 0.0 and PHYS["vy"] == 0.0
+
+
 def lookup_traffic(nx, ny, T, bc, rows=0):
     """PMC HBM bytes per launch of the sweep instantiation that was timed: same T, same local grid.
     Falls back to the per-cell figure of another grid of the same T (flagged) — the traffic per cell
@@ -193,7 +198,9 @@ def lookup_traffic(nx, ny, T, bc, rows=0):
         entries = json.load(open(f)).get("entries", [])
     except Exception:
         return None, "profiles/pmc_traffic.json missing"
-    same_t = [e for e in entries if e.get("steps_per_launch") == T]
+    # the diffusion-only flavour is its own instantiation, k_sweepO_dpp<DIV, T, 2, 2>
+    still = diffusion_only() and T >= 2
+    same_t = [e for e in entries if e.get("steps_per_launch") == T and (", 2, 2>" in e.get("kernel", "")) == still]
     exact = [e for e in same_t if e.get("nx") == nx and e.get("ny") == ny]
     pick = [e for e in exact if e.get("bc") == bc] or exact
     if pick:
@@ -318,6 +325,9 @@ def main():
     ap.add_argument("--nx", type=int, default=NX)
     ap.add_argument("--ny", type=int, default=NY)
     ap.add_argument("--bc", default=BC, help="boundary mix left/right/bottom/top, e.g. dddd (default), nnnn, dnpd")
+    ap.add_argument("--physics", default=None,
+                    help="D,vx,vy,dt instead of the headline workload's 0.05,0.5,0.25,0.1 — e.g. 1.0,0,0,0.1 with --nx 4096 --ny 4096 "
+                         "--bc pppp = BASELINE configs[1] (diffusion only: the sweep's seven-operation flavour, HBM-bound)")
     ap.add_argument("--contract", type=int, default=0,
                     help="0 (default): the reference's own operation order, bit-identical results; 1: opt-in "
                          "contracted arithmetic (see csim.h option \"contract\"), within 1e-10 of the reference")
@@ -340,6 +350,9 @@ def main():
                     help="watchdog: seconds a phase (one schedule's preflight or timed region) may take beyond its expected time")
     args = ap.parse_args()
     assert len(args.bc) == 4 and set(args.bc) <= set("dnp"), "--bc takes four of d/n/p"
+    if args.physics:
+        D_, vx_, vy_, dt_ = (float(v) for v in args.physics.split(","))
+        PHYS.update(D=D_, vx=vx_, vy=vy_, dt=dt_)
     assert args.repeats >= 1
 
     rank = int(os.environ.get("RANK", "0"))
@@ -850,7 +863,8 @@ def build_line(S):
     else:
         ach_bytes, ach_src = alg_bytes, "algorithmic_bytes_per_launch (no PMC entry: a LOWER bound of the real traffic)"
     ach = ach_bytes / secs / 1e9
-    valu_binds = T >= 4 and not args.contract
+    still = diffusion_only() and T >= 2 and not args.contract
+    valu_binds = T >= 4 and not args.contract and not still   # half the arithmetic: HBM binds
     roofline = {
         # this object prices the HBM side of the dominant kernel (the contract's schema); `is_binding` says whether
         # HBM is what limits it — at T >= 4 it is not: fp64 VALU issue is (roofline_valu)
@@ -867,7 +881,8 @@ def build_line(S):
         "achieved_from": ach_src,
         "traffic_source": traffic_src,
         "frac_of_measured_copy_peak": ach / HBM_COPY_GBS,
-        "kernel": kernel_label(T) + f" (fused copy+diffusion+advection, {T} time step(s) per HBM pass)",
+        "kernel": kernel_label(T) + (f" (fused copy+diffusion, advection term of zero velocity left out, {T} time step(s) per HBM pass)"
+                                     if still else f" (fused copy+diffusion+advection, {T} time step(s) per HBM pass)"),
         "kernel_avg_ms": kern_avg_ms,
         "kernel_avg_ms_is": "HIP events on the compute stream around each RUN of equal launches / launches in it, all timed "
                             "regions together (N = 1: includes the ~5 us ghost fills between launches where a side is "
@@ -886,9 +901,9 @@ def build_line(S):
                 "raising the throughput (16384^2: T = 6 ~0.55, T = 7 ~0.48 at +0.9 % Mcell-updates/s): the kernel is bound "
                 "by fp64 VALU issue (roofline_valu: VALUs ~95 % busy at the clock the chip holds), not by HBM",
     }
-    ops_per_update = FP64_OPS_PER_UPDATE if not args.contract else 5
+    ops_per_update = 5 if args.contract else 8 if still else FP64_OPS_PER_UPDATE   # diffusion only: the 8 operations of src/diffusion.cpp:9-16
     useful_tops = local_cells * T * ops_per_update / secs / 1e12
-    valu = lookup_valu(T) if not args.contract else None
+    valu = lookup_valu(T) if not (args.contract or still) else None
     roofline_valu = {
         "bound": "fp64-valu",
         "is_binding": valu_binds,

@@ -54,6 +54,22 @@ def test_bench_line_contract_single_gpu():
     assert cfg["stalled_schedule"] is None
 
 
+def test_bench_configs1_diffusion_only_periodic_checks_itself_and_prices_hbm():
+    """BASELINE configs[1] through bench.py (--physics 1.0,0,0,0.1 --bc pppp on 4096^2): the sweep's seven-operation
+    flavour; the preflight compares with the ORACLE's checksum of that very workload (tests/golden/bench_checksum.json),
+    and the line flags HBM, not the VALUs, as the binding resource"""
+    r = run_bench(["--nx", "4096", "--ny", "4096", "--bc", "pppp", "--physics", "1.0,0,0,0.1", "--steps", "63"])
+    cfg, rf = r["config"], r["roofline"]
+    assert "D=1.0" in cfg["workload"] and "v=(0.0,0.0)" in cfg["workload"] and "bc=pppp" in cfg["workload"]
+    pre = cfg["parity_preflight"]
+    assert pre["ok"] and pre["checksum_expected"] and not pre.get("fixture_mismatch")
+    (rec,) = pre["schedules"].values()
+    assert rec["checksum_ok"] is True and rec["checksum"] == pre["checksum_expected"]
+    assert rf["is_binding"] is True and r["roofline_valu"]["is_binding"] is False
+    assert "advection term of zero velocity left out" in rf["kernel"] and rf["time_steps_per_launch"] == 7
+    assert r["roofline_valu"]["useful_ops_per_cell_update"] == 8
+
+
 def test_bench_multi_rank_path_on_self_linked_torus():
     r = run_bench([], env={"CSIM_BENCH_SELF_TORUS": "1"})
     cfg = r["config"]

@@ -24,7 +24,7 @@ PHYS = dict(D=0.05, vx=0.5, vy=0.25, dt=0.1)   # bench.py PHYS
 CHECK_STEPS = (1, 7, 32)                       # bench.py CHECK_STEPS
 
 
-def entry(csim, nx, ny, bc):
+def entry(csim, nx, ny, bc, PHYS=PHYS):
     st = csim.Stepper.single(nx, ny, 1.0, 1.0, csim.bc_codes(bc))
     st.init_gaussian(1.0, 0.05, 0.5, 0.5)
     ic = st.download()
@@ -55,6 +55,9 @@ def main():
     csim.set_device(0)
     grids = [(16384, 16384, "dddd"), (16384, 16384, "nnnn"), (16384, 16384, "dnpd"), (1536, 1024, "dddd")]
     entries = [entry(csim, *g) for g in grids]
+    # BASELINE configs[1] (diffusion only, all Periodic) and the same physics on the bench grid: bench.py --physics 1.0,0,0,0.1
+    still = dict(D=1.0, vx=0.0, vy=0.0, dt=0.1)
+    entries += [entry(csim, 4096, 4096, "pppp", still), entry(csim, 16384, 16384, "pppp", still)]
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     json.dump(dict(note="position-weighted 64-bit checksum (csim_stepper_checksum) of the bench field after 1 + 7 + 32 steps, "
                         "computed by the oracle; see tools/make_bench_checksum.py", entries=entries),
