@@ -326,7 +326,8 @@ def main():
     ap.add_argument("--ny", type=int, default=NY)
     ap.add_argument("--bc", default=BC, help="boundary mix left/right/bottom/top, e.g. dddd (default), nnnn, dnpd")
     ap.add_argument("--physics", default=None,
-                    help="D,vx,vy,dt instead of the headline workload's 0.05,0.5,0.25,0.1 — e.g. 1.0,0,0,0.1 with --nx 4096 --ny 4096 "
+                    help="D,dt,vx,vy (the order of csim_stepper_run, as in tools/torus_bench.py) instead of the headline workload's "
+                         "0.05,0.1,0.5,0.25 — e.g. 1.0,0.1,0,0 with --nx 4096 --ny 4096 "
                          "--bc pppp = BASELINE configs[1] (diffusion only: the sweep's seven-operation flavour, HBM-bound)")
     ap.add_argument("--contract", type=int, default=0,
                     help="0 (default): the reference's own operation order, bit-identical results; 1: opt-in "
@@ -351,7 +352,7 @@ def main():
     args = ap.parse_args()
     assert len(args.bc) == 4 and set(args.bc) <= set("dnp"), "--bc takes four of d/n/p"
     if args.physics:
-        D_, vx_, vy_, dt_ = (float(v) for v in args.physics.split(","))
+        D_, dt_, vx_, vy_ = (float(v) for v in args.physics.split(","))
         PHYS.update(D=D_, vx=vx_, vy=vy_, dt=dt_)
     assert args.repeats >= 1
 

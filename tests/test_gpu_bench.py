@@ -55,10 +55,10 @@ def test_bench_line_contract_single_gpu():
 
 
 def test_bench_configs1_diffusion_only_periodic_checks_itself_and_prices_hbm():
-    """BASELINE configs[1] through bench.py (--physics 1.0,0,0,0.1 --bc pppp on 4096^2): the sweep's seven-operation
+    """BASELINE configs[1] through bench.py (--physics 1.0,0.1,0,0 --bc pppp on 4096^2): the sweep's seven-operation
     flavour; the preflight compares with the ORACLE's checksum of that very workload (tests/golden/bench_checksum.json),
     and the line flags HBM, not the VALUs, as the binding resource"""
-    r = run_bench(["--nx", "4096", "--ny", "4096", "--bc", "pppp", "--physics", "1.0,0,0,0.1", "--steps", "63"])
+    r = run_bench(["--nx", "4096", "--ny", "4096", "--bc", "pppp", "--physics", "1.0,0.1,0,0", "--steps", "63"])
     cfg, rf = r["config"], r["roofline"]
     assert "D=1.0" in cfg["workload"] and "v=(0.0,0.0)" in cfg["workload"] and "bc=pppp" in cfg["workload"]
     pre = cfg["parity_preflight"]

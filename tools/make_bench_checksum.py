@@ -55,7 +55,7 @@ def main():
     csim.set_device(0)
     grids = [(16384, 16384, "dddd"), (16384, 16384, "nnnn"), (16384, 16384, "dnpd"), (1536, 1024, "dddd")]
     entries = [entry(csim, *g) for g in grids]
-    # BASELINE configs[1] (diffusion only, all Periodic) and the same physics on the bench grid: bench.py --physics 1.0,0,0,0.1
+    # BASELINE configs[1] (diffusion only, all Periodic) and the same physics on the bench grid: bench.py --physics 1.0,0.1,0,0
     still = dict(D=1.0, vx=0.0, vy=0.0, dt=0.1)
     entries += [entry(csim, 4096, 4096, "pppp", still), entry(csim, 16384, 16384, "pppp", still)]
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
