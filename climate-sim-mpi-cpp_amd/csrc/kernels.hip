@@ -106,12 +106,25 @@ __device__ __forceinline__ double cell(double c, double W, double E, double S, d
         return __builtin_fma(p.aN, N, o);
     }
     const double o = diffuse_term<DIV, FAST>(c, W, E, S, N, p);
-    // SX = SY = 2 — vx == 0 and vy == 0 (BASELINE configs[1], diffusion only): the reference still evaluates
-    // o + (-dt) * (0 * dudx + 0 * dudy).  With finite differences that term is +0 or -0, and o + (+-0) is o bit for
+    // SX = 2 / SY = 2 — vx == 0 / vy == 0 (both: BASELINE configs[1], diffusion only; one: e.g. the reference's own
+    // configs/dev.yaml, vy = 0).  The reference still evaluates o + (-dt) * (vx * dudx + vy * dudy).  With finite
+    // differences a product with a zero velocity is +0 or -0; adding it to the other product changes nothing unless that
+    // one is a zero too, and then only the SIGN of the zero sum; (-dt) times a zero is a zero; and o + (+-0) is o bit for
     // bit unless o is -0 — and c + k * lap can only be -0 where c itself is -0, level after level down to a LOADED -0.
-    // So the screened interior body (FAST: every loaded value finite and below the threshold; here also: none of them
-    // -0) leaves the seven advection operations out; every other body of that instantiation evaluates them as v >= 0.
-    if (FAST && SX == 2 && SY == 2) return o;
+    // So the screened interior body (FAST: every loaded value finite and below the threshold; here also: none of them -0)
+    // leaves the operations of a zero component out (3 of 14 for one, all 7 for both); every other body of such an
+    // instantiation evaluates them as v >= 0.
+    if (FAST && (SX == 2 || SY == 2)) {
+        if (SX == 2 && SY == 2) return o;
+        double g;  // the one live component, as advect_term forms it
+        if (SY == 2)
+            g = SX == 1 ? c - W : E - c;
+        else
+            g = SY == 1 ? c - S : N - c;
+        if (DIV == 1) g = g * (SY == 2 ? p.rdx : p.rdy);
+        const double adv = (SY == 2 ? p.vx : p.vy) * g;
+        return o + p.mdt * adv;
+    }
     return o + advect_term<DIV, (SX == 2 ? 1 : SX), (SY == 2 ? 1 : SY)>(c, W, E, S, N, p);
 }
 
@@ -478,7 +491,7 @@ __device__ __forceinline__ bool sweepO_march(const double* __restrict__ in, doub
     auto screen = [&](const double2& v) {
         big |= !(__builtin_fabs(v.x) < p.fast_thr);
         big |= !(__builtin_fabs(v.y) < p.fast_thr);
-        if (SX == 2 && SY == 2) {  // no-advection flavour (see cell): a loaded -0 sends the tile to the plain body too
+        if (SX == 2 || SY == 2) {  // flavours without (part of) the advection term (see cell): a loaded -0 sends the tile to the plain body too
             big |= __builtin_amdgcn_class(v.x, 0x20);
             big |= __builtin_amdgcn_class(v.y, 0x20);
         }
@@ -946,12 +959,18 @@ hipError_t sweepO_div(const double* in, double* out, int nx, int ny, int pitch, 
     if (DIV == 3) {  // coefficient form: the upwind directions are folded into the coefficients
         CSIM_LAUNCH_O(1, 1);
     } else {
-        // diffusion only (DIV 0 / 1; the IEEE-division form keeps its four sign flavours)
-        const bool still = DIV <= 1 && p.vx == 0.0 && p.vy == 0.0 && p.fast_thr > 0.0;
-        switch (still ? 4 : sign) {
-            case 4: if constexpr (DIV <= 1) CSIM_LAUNCH_O(2, 2); break;
-            case 3: CSIM_LAUNCH_O(1, 1); break;
-            case 2: CSIM_LAUNCH_O(1, 0); break;
+        // zero velocity components (DIV 0 / 1; the IEEE-division form keeps its four sign flavours): code 2 per axis
+        const bool screened = DIV <= 1 && p.fast_thr > 0.0;
+        const int cx = screened && p.vx == 0.0 ? 2 : (p.vx >= 0.0 ? 1 : 0), cy = screened && p.vy == 0.0 ? 2 : (p.vy >= 0.0 ? 1 : 0);
+        (void)sign;
+        switch (3 * cx + cy) {
+            case 8: if constexpr (DIV <= 1) CSIM_LAUNCH_O(2, 2); break;
+            case 7: if constexpr (DIV <= 1) CSIM_LAUNCH_O(2, 1); break;
+            case 6: if constexpr (DIV <= 1) CSIM_LAUNCH_O(2, 0); break;
+            case 5: if constexpr (DIV <= 1) CSIM_LAUNCH_O(1, 2); break;
+            case 2: if constexpr (DIV <= 1) CSIM_LAUNCH_O(0, 2); break;
+            case 4: CSIM_LAUNCH_O(1, 1); break;
+            case 3: CSIM_LAUNCH_O(1, 0); break;
             case 1: CSIM_LAUNCH_O(0, 1); break;
             default: CSIM_LAUNCH_O(0, 0); break;
         }

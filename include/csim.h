@@ -223,7 +223,8 @@ int csim_stepper_sum(csim_stepper* s, double* out);
  *                    With vx == vy == 0 (diffusion only, BASELINE configs[1]) the same screened body also leaves out
  *                    the advection term, whose value is then +-0 (7 instead of 14 operations per cell; a loaded -0
  *                    sends the tile to the reference's sequence, because o + (+0) would turn an o of -0 into +0).
- *                    "diffusion_only_active" (read-only): whether the last run swept that way
+ *                    "diffusion_only_active" (read-only): whether the last run swept that way.  One zero component alone:
+ *                    its three operations are left out under the same screen (11 per cell)
  *   "fuse"           time steps per HBM pass: -1 auto (the cheapest split of a run into passes of 2..7 steps, e.g.
  *                    1000 = 166 x 6 + 4, 20 = 7 + 7 + 6), 0/1 off, 2..7 balanced passes of at most that depth
  *   "variant"        single-step kernel family: 0 auto, 1 dpp, 2 lds, 3 naive

@@ -102,6 +102,33 @@ def test_zero_velocity_is_the_reference_bit_for_bit_signed_zeros_included(csim, 
             assert same_bits(got, want), (bc, vx, vy, on)
 
 
+@pytest.mark.parametrize("dx,dy", [(1.0, 1.0), (0.5, 2.0), (0.7, 1.3)])
+@pytest.mark.parametrize("fuse", [2, 4, 5, 6, 7, -1])
+def test_one_zero_velocity_component_is_the_reference_bit_for_bit(csim, dx, dy, fuse):
+    """vx = 0 or vy = 0 alone (the reference's own configs/dev.yaml has vy = 0): the screened interior body leaves the
+    three operations of the zero component out — same screen, same argument, both upwind directions of the live one"""
+    nx, ny = 700, 160
+    steps = 17 if fuse < 0 else fuse + 3
+    D = 0.05
+    for k, (bc, vx, vy, nonfinite) in enumerate([("dddd", 0.5, 0.0, True), ("npdn", -0.5, 0.0, False), ("pnnd", 0.0, 0.25, False),
+                                                 ("dnpd", 0.0, -0.25, False), ("dddd", 0.5, -0.0, False), ("nnnn", -0.0, -0.25, False)]):
+        dt = min(0.1, csim.safe_dt(dx, dy, vx, vy, D))
+        u0 = nasty_field(nx, ny, 40 + k, nonfinite)
+        want = u0.copy()
+        with np.errstate(all="ignore"):
+            ora.run_single(want, dx, dy, D, vx, vy, dt, ora.bc_codes(bc), steps)
+        for on in (1, 0):
+            st = csim.Stepper.single(nx, ny, dx, dy, csim.bc_codes(bc))
+            for key, v in dict(fuse=fuse, rows_per_chunk=18, fused_2c=on).items():
+                st.set_option(key, v)
+            st.upload(u0)
+            st.run(D, dt, vx, vy, steps)
+            assert st.get_option("diffusion_only_active") == 0
+            got = st.download()
+            st.close()
+            assert same_bits(got, want), (bc, vx, vy, on)
+
+
 def test_flavour_follows_the_velocity_from_run_to_run(csim):
     """one stepper, runs with v = 0 and v != 0 in turn: each run uses its own flavour (and re-tunes), results as the oracle's"""
     nx, ny = 1200, 900
@@ -110,7 +137,7 @@ def test_flavour_follows_the_velocity_from_run_to_run(csim):
     want = u0.copy()
     st = csim.Stepper.single(nx, ny, 1.0, 1.0, csim.bc_codes("dnpd"))
     st.upload(u0)
-    for vx, vy, steps in [(0.0, 0.0, 30), (0.5, -0.25, 23), (0.0, 0.0, 9), (0.0, 0.25, 8)]:
+    for vx, vy, steps in [(0.0, 0.0, 30), (0.5, -0.25, 23), (0.0, 0.0, 9), (0.0, 0.25, 8), (-0.5, 0.0, 15), (0.5, 0.25, 6)]:
         ora.run_single(want, 1.0, 1.0, D, vx, vy, dt, ora.bc_codes("dnpd"), steps)
         st.run(D, dt, vx, vy, steps)
         assert st.get_option("diffusion_only_active") == (1 if vx == 0.0 and vy == 0.0 else 0)
