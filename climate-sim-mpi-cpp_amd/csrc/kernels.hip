@@ -946,14 +946,12 @@ hipError_t sweepO_div(const double* in, double* out, int nx, int ny, int pitch, 
     tl.tail_blocks = cdiv(tail_tiles, 4);
     const dim3 grid(nblocks), block(256);
     const int sw = cfg.xcd_swizzle;
-    const int sign = (p.vx >= 0.0 ? 2 : 0) + (p.vy >= 0.0 ? 1 : 0);
     SweepArgs ka;
     ka.nx = nx, ka.ny = ny, ka.pitch = pitch, ka.nstrips = nstrips, ka.swz = sw;
     ka.tl = tl, ka.p = p, ka.bc = bc, ka.fin = fin, ka.fs = fs;
 #define CSIM_LAUNCH_O(SXV, SYV) \
     hipLaunchKernelGGL((k_sweepO_dpp<DIV, T, SXV, SYV>), grid, block, cfg.lds_bytes, st, in, out, ka)
 #ifdef CSIM_ISA_PROBE
-    (void)sign;
     CSIM_LAUNCH_O(1, 1);
 #else
     if (DIV == 3) {  // coefficient form: the upwind directions are folded into the coefficients
@@ -962,7 +960,6 @@ hipError_t sweepO_div(const double* in, double* out, int nx, int ny, int pitch, 
         // zero velocity components (DIV 0 / 1; the IEEE-division form keeps its four sign flavours): code 2 per axis
         const bool screened = DIV <= 1 && p.fast_thr > 0.0;
         const int cx = screened && p.vx == 0.0 ? 2 : (p.vx >= 0.0 ? 1 : 0), cy = screened && p.vy == 0.0 ? 2 : (p.vy >= 0.0 ? 1 : 0);
-        (void)sign;
         switch (3 * cx + cy) {
             case 8: if constexpr (DIV <= 1) CSIM_LAUNCH_O(2, 2); break;
             case 7: if constexpr (DIV <= 1) CSIM_LAUNCH_O(2, 1); break;
